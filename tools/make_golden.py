@@ -1,0 +1,376 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE (PyREMOT).
+
+Runs only in the build container, where /root/reference exists:
+
+    PYTHONPATH=/root/reference MPLBACKEND=Agg python3 tools/make_golden.py <what> [...]
+
+<what> in: setup rhs rk4 tight default n1 helpers all   (see SURVEY.md section 8(c), G1..G7).
+The reference never travels to the GPU box; only the small .npz/.json files written here do.
+Inputs come from tests/inputs.py (this repo's restatement of the reference's test inputs).
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import inputs as INP  # noqa: E402
+
+import PyREMOT  # noqa: E402  (the reference)
+from PyREMOT import rmtExe  # noqa: E402
+import PyREMOT.docs.pbHomoReactor as PBH  # noqa: E402
+from PyREMOT.docs.pbHomoReactor import PackedBedHomoReactorClass as PB  # noqa: E402
+from PyREMOT.solvers.solSetting import solverSetting  # noqa: E402
+from PyREMOT.solvers import odeSolver as ODES  # noqa: E402
+import scipy.integrate  # noqa: E402
+
+REAL_SOLVE_IVP = scipy.integrate.solve_ivp
+
+
+class _Captured(Exception):
+    pass
+
+
+@contextlib.contextmanager
+def quiet():
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        yield
+
+
+@contextlib.contextmanager
+def mesh(zNo=None, tNo=None, model="N2"):
+    old = dict(solverSetting[model])
+    if zNo is not None:
+        solverSetting[model]["zNo"] = zNo
+    if tNo is not None:
+        solverSetting[model]["tNo"] = tNo
+    try:
+        yield
+    finally:
+        solverSetting[model].clear()
+        solverSetting[model].update(old)
+
+
+def capture(mi, zNo):
+    """Run rmtExe up to the first solve_ivp call; return (IV, paramsSet)."""
+    box = {}
+
+    def fake(fun, t_span, y0, method=None, t_eval=None, args=None, **kw):
+        box["IV"] = np.array(y0, dtype=float)
+        box["params"] = args[0]
+        raise _Captured()
+
+    PBH.solve_ivp = fake
+    try:
+        with mesh(zNo), quiet():
+            try:
+                rmtExe(mi)
+            except _Captured:
+                pass
+    finally:
+        PBH.solve_ivp = REAL_SOLVE_IVP
+    return box["IV"], box["params"]
+
+
+def rhs(params, y):
+    return np.array(PB.modelEquationN2(0.0, np.array(y, dtype=float), params), dtype=float)
+
+
+def run_with_tol(mi, zNo, method, rtol=None, atol=None):
+    nfev = [0]
+
+    def wrapped(fun, t_span, y0, method=None, t_eval=None, args=None, **kw):
+        if rtol is not None:
+            kw["rtol"] = rtol
+        if atol is not None:
+            kw["atol"] = atol
+        sol = REAL_SOLVE_IVP(fun, t_span, y0, method=method, t_eval=t_eval, args=args, **kw)
+        nfev[0] += sol.nfev
+        return sol
+
+    mi = dict(mi)
+    mi["solver-config"] = dict(mi["solver-config"], ivp=method)
+    PBH.solve_ivp = wrapped
+    t0 = time.time()
+    try:
+        with mesh(zNo), quiet():
+            res = rmtExe(mi)
+    finally:
+        PBH.solve_ivp = REAL_SOLVE_IVP
+    return res, nfev[0], time.time() - t0
+
+
+def pack_datapack(res):
+    dp = res["resModel"]["dataPack"]
+    out = {}
+    for k, d in enumerate(dp):
+        for key in ("dataYs", "dataYCons1", "dataYCons2", "dataYTemp1", "dataYTemp2", "dataXs"):
+            out["%s_%d" % (key, k)] = np.array(d[key], dtype=float)
+        out["dataTime_%d" % k] = np.array(float(d["dataTime"]))
+    out["n"] = np.array(len(dp))
+    return out
+
+
+def tolist(v):
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    if isinstance(v, (np.floating, np.integer)):
+        return v.item()
+    if isinstance(v, (list, tuple)):
+        return [tolist(x) for x in v]
+    if isinstance(v, dict):
+        return {k: tolist(x) for k, x in v.items() if not callable(x)}
+    return v
+
+
+def synthetic_states(IV, V, N, seed):
+    """Deterministic test states of the (V,N) layout: smooth profile, noisy, and one with
+    negative / tiny concentrations (exercises the EPS clamp, pbHomoReactor.py:3899,4093)."""
+    rng = np.random.default_rng(seed)
+    Y0 = IV.reshape(V, N)
+    z = np.linspace(0, 1, N)
+    states = []
+    s1 = Y0.copy()
+    for i in range(V):
+        if i < V - 1 or V == Y0.shape[0]:
+            s1[i] = Y0[i]*(1.0 + 0.15*np.sin(2.0*np.pi*(z + 0.1*i))) + 0.003*(i + 1)*z
+    s1[V - 1] = 0.02*z + 0.01*np.sin(3*np.pi*z)
+    states.append(s1)
+    s2 = np.abs(Y0*(1 + 0.05*rng.standard_normal(Y0.shape))) + 1e-4*rng.random(Y0.shape)
+    s2[V - 1] = 0.03*rng.random(N) - 0.005
+    states.append(s2)
+    s3 = s1.copy()
+    idx = rng.integers(0, N, size=max(2, N//10))
+    S = V - 1
+    s3[min(2, S - 1), idx] = -1e-3*rng.random(len(idx))
+    if S > 4:
+        s3[4, idx[::2]] = 0.0
+    s3[0, idx[1::2]] = -5e-2
+    states.append(s3)
+    return [s.flatten() for s in states]
+
+
+# --------------------------------------------------------------------------- G1
+def g_setup():
+    out = {}
+    for name, fn in INP.ALL_N2_INPUTS.items():
+        mi = fn()
+        IV, params = capture(mi, 20)
+        rls, rsc, FunParam, DAP, ptype = params
+        out[name] = {
+            "input": {
+                "concentration": tolist(np.array(mi["feed"]["concentration"], dtype=float)),
+                "volumetric-flowrate": float(mi["feed"]["volumetric-flowrate"]),
+            },
+            "const": tolist(FunParam["const"]),
+            "constBC1": tolist(FunParam["constBC1"]),
+            "ExHe": tolist(FunParam["ExHe"]),
+            "DimensionlessAnalysisParams": tolist(DAP),
+            "reactionListSorted": tolist(rls),
+            "reactionStochCoeff": tolist(rsc),
+            "processType": ptype,
+            "IV": IV.tolist(),
+        }
+    # iso-thermal variant of the notebook case
+    mi = INP.dme_notebook_input(process_type="iso-thermal")
+    IV, params = capture(mi, 20)
+    out["dme_nb_iso"] = {"const": tolist(params[2]["const"]), "IV": IV.tolist(),
+                         "DimensionlessAnalysisParams": tolist(params[3])}
+    with open(os.path.join(GOLD, "g1_setup.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("G1 written")
+
+
+# --------------------------------------------------------------------------- G2
+def g_rhs():
+    out = {}
+    cases = [("dme_nb", 20), ("dme_nb", 100), ("dme_nb", 1024), ("dme_script", 20),
+             ("dme_script", 100), ("ch4", 20), ("ch4", 100), ("syn12", 20), ("syn12", 100)]
+    for name, zNo in cases:
+        mi = INP.ALL_N2_INPUTS[name]()
+        IV, params = capture(mi, zNo)
+        V = params[2]["const"]["varNo"]
+        states = [IV] + synthetic_states(IV, V, zNo, seed=zNo + len(name))
+        if zNo == 1024:
+            states = states[:3]
+        Y = np.array(states)
+        t0 = time.time()
+        F = np.array([rhs(params, y) for y in Y])
+        print("G2 %s zNo=%d: %d RHS calls in %.1fs" % (name, zNo, len(Y), time.time() - t0))
+        out["%s_%d_y" % (name, zNo)] = Y
+        out["%s_%d_f" % (name, zNo)] = F
+    # iso-thermal variant
+    mi = INP.dme_notebook_input(process_type="iso-thermal")
+    IV, params = capture(mi, 20)
+    Y = np.array([IV] + [s.reshape(7, 20)[:6].flatten() for s in synthetic_states(
+        np.concatenate([IV, np.zeros(20)]), 7, 20, seed=5)])
+    out["dme_nb_iso_20_y"] = Y
+    out["dme_nb_iso_20_f"] = np.array([rhs(params, y) for y in Y])
+    # mid-transient states from the tight run (if present)
+    p = os.path.join(GOLD, "g4_tight_dme_script_lsoda.npz")
+    if os.path.exists(p):
+        g4 = np.load(p)
+        mi = INP.dme_script_input()
+        IV, params = capture(mi, 20)
+        Y = np.array([np.concatenate([g4["dataYCons1_%d" % k].flatten(),
+                                      g4["dataYTemp1_%d" % k].flatten()]) for k in range(5)])
+        out["dme_script_20_transient_y"] = Y
+        out["dme_script_20_transient_f"] = np.array([rhs(params, y) for y in Y])
+    np.savez_compressed(os.path.join(GOLD, "g2_rhs.npz"), **out)
+    print("G2 written")
+
+
+# --------------------------------------------------------------------------- G3
+def g_rk4():
+    out = {}
+    for name, zNo, h, n, stride in [("dme_nb", 20, 1e-5, 200, 1), ("dme_script", 20, 1e-5, 200, 1),
+                                    ("dme_nb", 100, 1e-5, 100, 10), ("ch4", 20, 1e-3, 200, 1),
+                                    ("syn12", 20, 1e-5, 100, 1)]:
+        mi = INP.ALL_N2_INPUTS[name]()
+        IV, params = capture(mi, zNo)
+        t0 = time.time()
+        traj = ODES.RK4(0.0, n*h, n, IV, PB.modelEquationN2, params)
+        print("G3 %s zNo=%d n=%d: %.1fs" % (name, zNo, n, time.time() - t0))
+        key = "%s_%d" % (name, zNo)
+        out[key + "_traj"] = traj[:, ::stride]
+        out[key + "_h"] = np.array(h)
+        out[key + "_n"] = np.array(n)
+        out[key + "_stride"] = np.array(stride)
+    np.savez_compressed(os.path.join(GOLD, "g3_rk4.npz"), **out)
+    print("G3 written")
+
+
+# --------------------------------------------------------------------------- G4/G5
+def g_tight(which):
+    name, method = which.split(":")
+    tol = {"lsoda": ("LSODA", 1e-10, 1e-12), "bdf": ("BDF", 1e-9, 1e-12)}[method]
+    mi = INP.ALL_N2_INPUTS[name]()
+    res, nfev, wall = run_with_tol(mi, 20, tol[0], tol[1], tol[2])
+    out = pack_datapack(res)
+    out["nfev"] = np.array(nfev)
+    out["wall"] = np.array(wall)
+    np.savez_compressed(os.path.join(GOLD, "g4_tight_%s_%s.npz" % (name, method)), **out)
+    print("G4 %s %s: nfev=%d wall=%.1fs" % (name, method, nfev, wall))
+
+
+def g_default(name):
+    mi = INP.ALL_N2_INPUTS[name]()
+    res, nfev, wall = run_with_tol(mi, 20, "LSODA")
+    out = pack_datapack(res)
+    out["nfev"] = np.array(nfev)
+    out["wall"] = np.array(wall)
+    out["computation_time"] = np.array(res["resModel"]["computation-time"])
+    np.savez_compressed(os.path.join(GOLD, "g5_default_%s.npz" % name), **out)
+    print("G5 %s: nfev=%d wall=%.1fs" % (name, nfev, wall))
+
+
+# --------------------------------------------------------------------------- G6
+def g_n1():
+    mi = INP.n1_notebook_input()
+    t0 = time.time()
+    with quiet():
+        res = rmtExe(mi)
+    d = res["resModel"][0]
+    out = {k: np.array(d[k], dtype=float) for k in
+           ("dataYs", "dataYCons1", "dataYCons2", "dataYTemp1", "dataYTemp2", "dataXs")}
+    out["wall"] = np.array(time.time() - t0)
+    # a few direct RHS probes of modelEquationN1
+    box = {}
+
+    def fake(fun, t_span, y0, method=None, t_eval=None, args=None, **kw):
+        box["IV"] = np.array(y0, float)
+        box["params"] = args[0]
+        raise _Captured()
+    PBH.solve_ivp = fake
+    try:
+        with quiet():
+            try:
+                rmtExe(mi)
+            except _Captured:
+                pass
+    finally:
+        PBH.solve_ivp = REAL_SOLVE_IVP
+    IV = box["IV"]
+    ys = [IV, d["dataYCons1"][:, 50].tolist() + [d["dataYs"][6, 50]/5e6, d["dataYTemp1"][50]],
+          d["dataYCons1"][:, 100].tolist() + [d["dataYs"][6, 100]/5e6, d["dataYTemp1"][100]]]
+    ys = np.array([np.array(y, float) for y in ys])
+    with quiet():
+        fs = np.array([PB.modelEquationN1(0.37, y, box["params"]) for y in ys])
+    out["rhs_y"] = ys
+    out["rhs_f"] = fs
+    np.savez_compressed(os.path.join(GOLD, "g6_n1.npz"), **out)
+    print("G6 written")
+
+
+# --------------------------------------------------------------------------- G7
+def g_helpers():
+    from PyREMOT.docs.rmtThermo import (calHeatCapacityAtConstantPressure,
+                                        calMeanHeatCapacityAtConstantPressure,
+                                        calMixtureHeatCapacityAtConstantPressure,
+                                        calStandardEnthalpyOfReaction,
+                                        calEnthalpyChangeOfReaction)
+    from PyREMOT.docs.gasTransPor import calGasViscosity, calMixturePropertyM1
+    from PyREMOT.docs.rmtUtility import rmtUtilityClass as U
+    from PyREMOT.data import componentSymbolList, componentDataStore
+    comps = list(componentSymbolList)
+    out = {"components": comps, "MW": [c["MW"] for c in componentDataStore["payload"]],
+           "dHf25": [c["dHf25"]["val"] for c in componentDataStore["payload"]], "probes": []}
+    mf = np.arange(1, len(comps) + 1, dtype=float)
+    mf = mf/mf.sum()
+    MW = np.array(out["MW"])
+    for T in (298.15, 400.0, 523.0, 700.0, 973.0):
+        cp = calHeatCapacityAtConstantPressure(comps, T)
+        cpm = calMeanHeatCapacityAtConstantPressure(comps, T)
+        vis = calGasViscosity(comps, T)
+        out["probes"].append({
+            "T": T, "Cp": cp.tolist(), "CpMean": cpm.tolist(),
+            "CpMix": float(calMixtureHeatCapacityAtConstantPressure(mf, cpm)),
+            "GaVii": vis.tolist(),
+            "GaMiVi": float(calMixturePropertyM1(len(comps), vis, mf, MW)),
+        })
+    out["molefrac"] = mf.tolist()
+    rx = dict(INP.SYN12_REACTIONS)
+    rls = U.buildReactionCoefficient(rx)
+    out["reactions"] = rx
+    out["reactionListSorted"] = tolist(rls)
+    out["reactionStochCoeff"] = tolist(U.buildReactionCoeffVector(rls))
+    out["StHeRe25"] = [float(calStandardEnthalpyOfReaction(r)) for r in rx.values()]
+    out["EnChList_600"] = [float(v) for v in calEnthalpyChangeOfReaction(rls, 600.0)]
+    with open(os.path.join(GOLD, "g7_helpers.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("G7 written")
+
+
+def main(argv):
+    os.makedirs(GOLD, exist_ok=True)
+    for what in argv:
+        if what == "setup":
+            g_setup()
+        elif what == "rhs":
+            g_rhs()
+        elif what == "rk4":
+            g_rk4()
+        elif what.startswith("tight="):
+            g_tight(what.split("=", 1)[1])
+        elif what.startswith("default="):
+            g_default(what.split("=", 1)[1])
+        elif what == "n1":
+            g_n1()
+        elif what == "helpers":
+            g_helpers()
+        else:
+            raise SystemExit("unknown target " + what)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - mesh-node-steps/s of the N2 hot path on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE configs[1]'s reactor - the TEST2.ipynb DME case (6 species,
+3 reactions, fp64) on 1024 axial nodes, classic RK4 with dt = 1e-5 s - replicated as the
+per-GPU shard of configs[3]'s ensemble: 256 independent reactors per GPU with the inlet-T /
+pressure sweep of SURVEY.md section 8(d).4 (2048 members at 8 GPUs).  One "step" = one RK4 time
+step (4 RHS evaluations) of every node of every member on this rank.  Ranks are independent
+(weak scaling, no data-path collective): rank 0 broadcasts the packed constants once (RCCL),
+outlet rows are gathered at the end.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = total mesh-node-steps/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+N_NODES = 1024
+MEMBERS_PER_GPU = 256
+DT = 1e-5
+
+
+def sweep_member_inputs(first, count, total=2048):
+    """Members first..first+count-1 of the 64 (T) x 32 (P) sweep:
+    member = iT*32 + iP, T in linspace(503,543,64), P in linspace(3e6,7e6,32); feed concentrations
+    y0*P/(R*T) with the config-2 mole fractions."""
+    import inputs as INP
+    base = INP.dme_notebook_input()
+    c0 = np.array(base["feed"]["concentration"], dtype=float)
+    y0 = c0/c0.sum()
+    Ts, Ps = np.linspace(503.0, 543.0, 64), np.linspace(3.0e6, 7.0e6, 32)
+    out = []
+    for mem in range(first, first + count):
+        m = mem % total
+        T, P = float(Ts[m // 32]), float(Ps[m % 32])
+        mi = INP.dme_notebook_input()
+        mi["operating-conditions"]["temperature"] = T
+        mi["operating-conditions"]["pressure"] = P
+        mi["feed"]["concentration"] = y0*P/(INP.R_CONST*T)
+        out.append(mi)
+    return out
+
+
+def cpu_baseline(mech, rows, IV, seconds=12.0):
+    """The oracle side, timed on this box's host cores: host emulation of the same generated
+    source (oracle/hostemu_driver.cpp, OpenMP over members) running the identical RK4."""
+    from oracle.hostemu import HostEmu
+    from rmt_app_amd import hipbind
+    emu = HostEmu(mech.source(hipbind.kernel_template()), tag="bench")
+    cores = os.cpu_count() or 1
+    E = min(len(rows), max(cores, 8))
+    y = IV[:E].copy()
+    emu.rk4(y, rows[:E], N_NODES, DT, 2)          # warm-up
+    steps, t_used = 0, 0.0
+    n = 20
+    while t_used < seconds:
+        t0 = time.perf_counter()
+        y, _ = emu.rk4(y, rows[:E], N_NODES, DT, n)
+        t_used += time.perf_counter() - t0
+        steps += n
+    return {"value": E*N_NODES*steps/t_used, "unit": "mesh-node-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d members x %d nodes x %d RK4 steps (%.1f s), host emulation of the "
+                      "generated kernel source, g++ -O2 -fopenmp" % (E, N_NODES, steps, t_used)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--members", type=int, default=MEMBERS_PER_GPU, help="reactors per GPU")
+    ap.add_argument("--nodes", type=int, default=N_NODES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="auto", choices=["auto", "reg", "mem"])
+    ap.add_argument("--block", type=int, default=None)
+    ap.add_argument("--npt", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from rmt_app_amd import plan
+    from rmt_app_amd.n2 import N2Device
+    global N_NODES
+    N_NODES = args.nodes
+    E = args.members
+    inputs = sweep_member_inputs(rank*E, E, total=max(2048, world*E))
+    mech = plan.Mechanism(inputs[0])
+    pairs = [plan.member_constants(mi, mech, N_NODES) for mi in inputs]
+    rows = np.array([r for _, r in pairs])
+    if distributed:
+        # rank 0 owns the packed mechanism constants; broadcast over RCCL so every rank integrates
+        # with bit-identical tables (member rows stay rank-local: the sweep is index-derived).
+        tab = torch.tensor(np.concatenate([mech.nu.ravel(), mech.cp_coeff.ravel(), mech.StHeRe25]),
+                           device="cuda")
+        dist.broadcast(tab, src=0)
+    IV = np.array([plan.initial_state(nm, mech, N_NODES) for nm, _ in pairs])
+    dev = N2Device(mech, rows, N_NODES, block=args.block, npt=args.npt)
+    dev.set_mode(args.mode)
+    y = dev.to_device(IV)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    dev.rk4(y, DT, args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    dev.rk4(y, DT, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = dev.last_kernel_ms()
+    flags = dev.status()
+    if flags.any():
+        raise SystemExit("device flags set during the bench: %s" % flags[flags != 0][:4])
+    tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+    if distributed:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+    # outlet rows (mole fractions need concentrations only) gathered for the record
+    outlet = y.reshape(E, mech.V, N_NODES)[:, :, -1].contiguous()
+    if distributed:
+        gathered = [torch.empty_like(outlet) for _ in range(world)] if rank == 0 else None
+        dist.gather(outlet, gathered, dst=0)
+
+    if rank == 0:
+        node_steps = world*E*N_NODES*args.steps
+        value = node_steps/tmax
+        bytes_per_node_step = 2*(mech.S + 2)*8
+        achieved = (E*N_NODES*args.steps*bytes_per_node_step/1e9)/(kernel_ms/1e3)
+        line = {
+            "metric": "mesh-node-steps/s (6-sp DME dynamic model)",
+            "value": value, "unit": "mesh-node-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3*tmax/args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "DME N2 (TEST2.ipynb reactor), %d nodes, RK4 dt=1e-5 s, %d "
+                                   "reactors/GPU of the 64x32 inlet-T/P sweep" % (N_NODES, E),
+                       "members_per_gpu": E, "nodes": N_NODES, "integrator": "rk4",
+                       "parallelism": "ensemble-dp%d" % world,
+                       "kernel": "rmt_n2_rk4_%s block=%d npt=%d" % (
+                           "reg" if (args.mode != "mem" and N_NODES <= dev.block*dev.npt) else "mem",
+                           dev.block, dev.npt)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(mech, rows, IV)
+        print(json.dumps(line))
+    dev.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

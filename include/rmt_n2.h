@@ -1,0 +1,115 @@
+/*
+ * rmt_n2.h - C ABI of the MI355X-native integrator for PyREMOT's dynamic packed-bed model "N2".
+ *
+ * The reference (sinagilassi/rmt-app, pure Python) has no FFI; its boundary for this path is the
+ * Python-level contract listed in SURVEY.md section 8(b).  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference repo):
+ *
+ *   rmt_n2_compile      - (new) lowers nothing itself: turns the host-generated kernel source
+ *                         (lowered `reaction-rates` lambdas + mechanism tables) into a gfx950 code
+ *                         object.  Replaces the per-call Python evaluation of the lambdas in
+ *                         reactionRateExe, PyREMOT/docs/rmtReaction.py:11-61.
+ *   rmt_n2_create       - the setup half of PackedBedHomoReactorClass.runN2,
+ *                         PyREMOT/docs/pbHomoReactor.py:3334-3580 (paramsSet construction): takes
+ *                         the packed per-reactor constants instead of nested dicts.
+ *   rmt_n2_rhs          - PackedBedHomoReactorClass.modelEquationN2(t, y, paramsSet),
+ *                         PyREMOT/docs/pbHomoReactor.py:3706-4134 (one RHS evaluation).
+ *   rmt_n2_rk4          - RK4(t0, tn, n, y0, f, params), PyREMOT/solvers/odeSolver.py:17-40, as used
+ *                         from the `ivp == "AM"` plug point pbHomoReactor.py:3598-3607 (only the
+ *                         last column - the end state - is produced, which is all runN2 keeps,
+ *                         :3630, :3685).
+ *   rmt_n2_rk45         - scipy.integrate.solve_ivp(funSet, t, IV, method=..., args=(paramsSet,))
+ *                         at pbHomoReactor.py:3609-3610, restricted to an explicit embedded pair
+ *                         (Dormand-Prince 5(4)) with per-reactor step control.
+ *   rmt_n2_status       - the exceptions Python raises inside the user lambdas / `raise` at
+ *                         pbHomoReactor.py:3614-3626, as per-reactor flag words.
+ *
+ * Conventions: every function returns 0 on success, non-zero on error (rmt_n2_last_error() gives
+ * a thread-local message).  `y`, `dydt` and `flags` are DEVICE pointers owned by the caller;
+ * plan contents are HOST memory, copied during rmt_n2_create.  Work is enqueued on the stream set
+ * with rmt_n2_set_stream (default: the null stream) and is NOT synchronised by these calls.
+ * State layout: y[E][V][N] = the reference's row-major flattening of the (V, N) matrix
+ * (pbHomoReactor.py:3483-3497, 3873) for each of E independent reactors; V = S (+1 unless
+ * iso-thermal); real = double, or float when the code object was generated with fp32.
+ * A handle is bound to the device that was current at create time; handles are not thread-safe,
+ * distinct handles are independent.  No global state besides the last-error string.
+ */
+#ifndef RMT_N2_H
+#define RMT_N2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMT_N2_ABI_VERSION 1
+
+/* status bits written by the kernels (OR-ed per reactor) */
+#define RMT_N2_FLAG_DOMAIN 1u    /* Python: ValueError("math domain error")          */
+#define RMT_N2_FLAG_DIV0 2u      /* Python: ZeroDivisionError                         */
+#define RMT_N2_FLAG_OVERFLOW 4u  /* Python: OverflowError("math range error")         */
+#define RMT_N2_FLAG_NONFINITE 8u /* a state/derivative became NaN or Inf              */
+#define RMT_N2_FLAG_STEP 16u     /* rk45: step size underflow / max steps exceeded    */
+
+/* member row layout: doubles per reactor = 16 + S (see rmt_app_amd/csrc/n2_kernels.inc M_*) */
+#define RMT_N2_MEMBER_FIXED 16
+
+typedef struct rmt_n2_plan {
+    int32_t abi_version;     /* RMT_N2_ABI_VERSION */
+    int32_t n_species;       /* S */
+    int32_t n_reactions;     /* R (informational) */
+    int32_t n_vars;          /* V = S or S+1 */
+    int32_t n_nodes;         /* N (zNo) */
+    int32_t n_members;       /* E */
+    int32_t fp32;            /* 1: real = float */
+    int32_t block;           /* RMT_BLOCK the code object was generated with */
+    int32_t nodes_per_thread;/* RMT_NPT the code object was generated with */
+    int32_t reserved;
+    const void* code_object; /* gfx950 code object from rmt_n2_compile (host memory) */
+    size_t code_size;
+    const double* members;   /* host [E][16+S] packed constants */
+} rmt_n2_plan;
+
+typedef struct rmt_n2_handle rmt_n2_handle;
+
+typedef struct rmt_n2_stats {   /* per reactor, written by rmt_n2_rk45 (device memory) */
+    double t_end;
+    double h_last;
+    int64_t accepted;
+    int64_t rejected;
+} rmt_n2_stats;
+
+/* hipRTC: source text -> code object for `arch` (e.g. "gfx950"); works without a GPU.
+ * *code is malloc'ed (free with rmt_n2_free); *log (may be NULL) receives the compiler log. */
+int rmt_n2_compile(const char* source, const char* arch, const char* extra_opts, void** code,
+                   size_t* code_size, char** log);
+void rmt_n2_free(void* p);
+/* the device template that rmt_n2_compile expects to follow the generated prelude */
+const char* rmt_n2_kernel_template(void);
+
+int rmt_n2_create(const rmt_n2_plan* plan, rmt_n2_handle** out);
+void rmt_n2_destroy(rmt_n2_handle* h);
+int rmt_n2_set_stream(rmt_n2_handle* h, void* hip_stream);
+/* replace the per-member constants (same E) without recompiling */
+int rmt_n2_set_members(rmt_n2_handle* h, const double* members);
+
+int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt);
+int rmt_n2_rk4(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t nsteps);
+int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
+                double h0, int64_t max_steps, rmt_n2_stats* stats_out);
+/* copies the E flag words to host memory (synchronises the stream) and clears them on device */
+int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
+/* which stepper rmt_n2_rk4 uses: 0 = auto, 1 = register-resident, 2 = memory-resident */
+int rmt_n2_set_mode(rmt_n2_handle* h, int mode);
+/* timing of the last rk4/rk45/rhs launch in ms (HIP events on the handle's stream; synchronises) */
+int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms);
+
+const char* rmt_n2_last_error(void);
+int rmt_n2_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMT_N2_H */

@@ -1,0 +1,58 @@
+"""TEST INFRASTRUCTURE ONLY: build and call the host emulation of the generated kernel source
+(see hostemu_driver.cpp).  Used by tests/ and by bench.py's cpu_baseline leg - never by the product.
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+
+class HostEmu:
+    def __init__(self, source, tag="emu", openmp=True):
+        os.makedirs(_BUILD, exist_ok=True)
+        key = hashlib.sha256((source + open(os.path.join(_HERE, "hostemu_driver.cpp")).read()
+                              ).encode()).hexdigest()[:16]
+        gen = os.path.join(_BUILD, "%s_%s.inc" % (tag, key))
+        so = os.path.join(_BUILD, "lib%s_%s.so" % (tag, key))
+        if not os.path.exists(so):
+            with open(gen, "w") as f:
+                f.write(source)
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                   "-DRMT_GENERATED_SOURCE=\"%s\"" % gen,
+                   os.path.join(_HERE, "hostemu_driver.cpp"), "-o", so + ".tmp"]
+            if openmp:
+                cmd.insert(1, "-fopenmp")
+            subprocess.run(cmd, check=True, capture_output=True)
+            os.replace(so + ".tmp", so)
+        self.lib = C.CDLL(so)
+        S, R, V, fp32 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.lib.emu_sizes(C.byref(S), C.byref(R), C.byref(V), C.byref(fp32))
+        self.S, self.R, self.V, self.fp32 = S.value, R.value, V.value, bool(fp32.value)
+        self.dtype = np.float32 if self.fp32 else np.float64
+        vp = C.c_void_p
+        self.lib.emu_rhs.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+        self.lib.emu_rhs.restype = None
+        self.lib.emu_rk4.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_longlong, vp]
+        self.lib.emu_rk4.restype = None
+
+    def rhs(self, y, members, N):
+        y = np.ascontiguousarray(y, dtype=self.dtype).reshape(-1, self.V*N)
+        E = y.shape[0]
+        members = np.ascontiguousarray(members, dtype=np.float64).reshape(E, -1)
+        out = np.empty_like(y)
+        flags = np.zeros(E, dtype=np.uint32)
+        self.lib.emu_rhs(y.ctypes.data, out.ctypes.data, members.ctypes.data, N, E, flags.ctypes.data)
+        return out, flags
+
+    def rk4(self, y, members, N, h, nsteps):
+        y = np.array(y, dtype=self.dtype).reshape(-1, self.V*N)
+        E = y.shape[0]
+        members = np.ascontiguousarray(members, dtype=np.float64).reshape(E, -1)
+        flags = np.zeros(E, dtype=np.uint32)
+        self.lib.emu_rk4(y.ctypes.data, members.ctypes.data, N, E, float(h), int(nsteps), flags.ctypes.data)
+        return y, flags

@@ -1,0 +1,81 @@
+// TEST INFRASTRUCTURE ONLY (lives under oracle/, never linked into the product library).
+//
+// Compiles the SAME generated source the GPU gets (prelude + n2_kernels.inc with the lowered
+// kinetics) for the host with g++, using only its per-node physics (rmt_node_pre/rmt_node_post)
+// and a plain sequential driver: pressure marched node by node exactly like the reference's loop
+// (PyREMOT/docs/pbHomoReactor.py:3892-3979), RK4 as PyREMOT/solvers/odeSolver.py:17-40.
+// Purpose: (1) CPU-side check of the lowering + kernel arithmetic against the oracle before any
+// GPU run, (2) the "fair" multi-core CPU baseline of bench.py (OpenMP over ensemble members).
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+#define RMT_HOST_EMULATION 1
+#define __device__
+#define __forceinline__ inline
+#define __restrict__
+using std::trunc;
+#include RMT_GENERATED_SOURCE
+
+static void emu_rhs_one(const RmtMember& m, const real* y, real* dydt, int N, unsigned& flag) {
+    preal P = m.p0;
+    real up[RMT_V];
+    for (int i = 0; i < RMT_S; ++i) up[i] = m.cin[i];
+#if !RMT_ISO
+    up[RMT_S] = m.theta_in;
+#endif
+    for (int z = 0; z < N; ++z) {
+        real ys[RMT_V], k[RMT_V];
+        for (int i = 0; i < RMT_V; ++i) ys[i] = y[(size_t)i * N + z];
+        RmtNode nd;
+        const preal a = rmt_node_pre(m, ys, nd);
+        rmt_node_post(m, nd, ys, up, P, k, flag);
+        for (int i = 0; i < RMT_V; ++i) dydt[(size_t)i * N + z] = k[i];
+        P = a * P + m.beta;
+        for (int i = 0; i < RMT_S; ++i) up[i] = rmt_max(ys[i], RMT_EPS);
+#if !RMT_ISO
+        up[RMT_S] = ys[RMT_S];
+#endif
+    }
+}
+
+extern "C" int emu_sizes(int* S, int* R, int* V, int* fp32) {
+    *S = RMT_S; *R = RMT_R; *V = RMT_V; *fp32 = RMT_FP32;
+    return 0;
+}
+
+extern "C" void emu_rhs(const real* y, real* dydt, const double* members, int N, int E, unsigned* flags) {
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < E; ++e) {
+        RmtMember m;
+        rmt_load_member(members + (size_t)e * RMT_NM, m);
+        unsigned f = 0;
+        emu_rhs_one(m, y + (size_t)e * RMT_V * N, dydt + (size_t)e * RMT_V * N, N, f);
+        flags[e] |= f;
+    }
+}
+
+extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_, long long nsteps,
+                        unsigned* flags) {
+    const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int e = 0; e < E; ++e) {
+        RmtMember m;
+        rmt_load_member(members + (size_t)e * RMT_NM, m);
+        const size_t n = (size_t)RMT_V * N;
+        real* y0 = y + e * n;
+        std::vector<real> ys(n), k(n), acc(n);
+        unsigned f = 0;
+        for (long long s = 0; s < nsteps; ++s) {
+            emu_rhs_one(m, y0, k.data(), N, f);
+            for (size_t i = 0; i < n; ++i) { acc[i] = k[i]; ys[i] = y0[i] + k[i] * hh; }
+            emu_rhs_one(m, ys.data(), k.data(), N, f);
+            for (size_t i = 0; i < n; ++i) { acc[i] += real(2) * k[i]; ys[i] = y0[i] + k[i] * hh; }
+            emu_rhs_one(m, ys.data(), k.data(), N, f);
+            for (size_t i = 0; i < n; ++i) { acc[i] += real(2) * k[i]; ys[i] = y0[i] + k[i] * h; }
+            emu_rhs_one(m, ys.data(), k.data(), N, f);
+            for (size_t i = 0; i < n; ++i) y0[i] += h6 * (acc[i] + k[i]);
+        }
+        flags[e] |= f;
+    }
+}

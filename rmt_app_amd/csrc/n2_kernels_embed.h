@@ -1,0 +1,509 @@
+R"RMTSRC(// =====================================================================================
+// rmt N2 device template (gfx950 / CDNA4, wave64).  Compiled at run time by hipRTC after a
+// host-generated prelude that defines:
+//
+//   RMT_S, RMT_R            species / reactions            RMT_ISO   1 = iso-thermal (V = S)
+//   RMT_FP32                1 = state & kinetics in fp32   RMT_BLOCK threads per workgroup
+//   RMT_NPT                 nodes per thread of the register-resident steppers
+//   typedef ... real;       double or float
+//   RMT_MW[S]               molecular weights [g/mol]
+//   RMT_CP[S][4]            Cp(T) = a + b T + c T^2 + d T^3  [J/mol/K]
+//   RMT_CPREF[S]            Cp(Tref)
+//   RMT_NU[R][S]            stoichiometric matrix (sum over all occurrences of a species)
+//   RMT_DH25[R]             standard heats of reaction [J/mol]
+//   rmt_kinetics(T,P,x,C,r,flag)   lowered user rate lambdas
+//
+// What it computes: the method-of-lines right-hand side of PyREMOT's model N2
+// (modelEquationN2, PyREMOT/docs/pbHomoReactor.py:3706-4134; equations restated in SURVEY.md
+// Appendix A) for one axial mesh node per lane (RMT_NPT consecutive nodes per lane), and
+// explicit time steppers on top of it (RK4 tableau of PyREMOT/solvers/odeSolver.py:17-40;
+// Dormand-Prince 5(4) with per-reactor step control).
+//
+// Layout: state y[E][V][N] (the reference's row-major (V,N) flattening per reactor, reactors
+// stacked), per-member constants members[E][RMT_NM] (see M_* below).  One workgroup integrates
+// one reactor: the sequential Ergun pressure march  P[z+1] = a_z P[z] + b  (:3979) is an affine
+// prefix scan (wave shuffles + one LDS exchange per stage), the upwind neighbour z-1 comes from
+// lane-1 (shuffle) or the previous wave (same LDS exchange).  No inter-workgroup communication.
+// =====================================================================================
+
+#define RMT_V (RMT_S + (RMT_ISO ? 0 : 1))
+#define RMT_NW (RMT_BLOCK / 64)
+#define RMT_NM (16 + RMT_S)
+
+#define RMT_FLAG_DOMAIN 1u
+#define RMT_FLAG_DIV0 2u
+#define RMT_FLAG_OVERFLOW 4u
+#define RMT_FLAG_NONFINITE 8u
+#define RMT_FLAG_STEP 16u
+
+// member row layout (doubles); host side: rmt_app_amd/plan.py MEMBER_FIELDS
+#define M_CMAX 0        // max(SpCoi0)                     [mol/m^3]
+#define M_TF 1          // feed temperature                [K]
+#define M_P0 2          // inlet pressure                  [Pa]
+#define M_THETA_IN 3    // (T0-Tf)/Tf
+#define M_ALPHA_K 4     // dz*1.75*vf^2*ergD/(dp*R):   a_z = 1 - ALPHA_K*M_z/T_z
+#define M_BETA 5        // -dz*ergA*ergB
+#define M_RHO_K 6       // 1/(R*GaDe0):                rho* = P*M/T*RHO_K
+#define M_INV_CP0 7     // 1/GaCpMeanMix0
+#define M_F1 8          // vf/(eps*zf)
+#define M_FT 9          // vf/zf
+#define M_INV_DZ 10     // N-1
+#define M_INV_MACOTE 11 // 1/GaMaCoTe0
+#define M_INV_HECOTE 12 // 1/GaHeCoTe0
+#define M_UA 13         // U*a
+#define M_TM 14         // medium temperature, 0 = adiabatic
+#define M_CIN 16        // S inlet values SpCoi0[i]/Cmax
+
+typedef double preal;   // the pressure scan is always carried in fp64
+
+#define RMT_EPS real(1e-30)
+#define RMT_TREF real(298.15)
+
+// ------------------------------------------------------------------ math wrappers
+__device__ __forceinline__ double rmt_exp(double x) { return exp(x); }
+__device__ __forceinline__ double rmt_exp10(double x) { return exp10(x); }
+__device__ __forceinline__ double rmt_exp2(double x) { return exp2(x); }
+__device__ __forceinline__ double rmt_expm1(double x) { return expm1(x); }
+__device__ __forceinline__ double rmt_log(double x) { return log(x); }
+__device__ __forceinline__ double rmt_log10(double x) { return log10(x); }
+__device__ __forceinline__ double rmt_log2(double x) { return log2(x); }
+__device__ __forceinline__ double rmt_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ double rmt_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ double rmt_abs(double x) { return fabs(x); }
+__device__ __forceinline__ double rmt_pow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ double rmt_sin(double x) { return sin(x); }
+__device__ __forceinline__ double rmt_cos(double x) { return cos(x); }
+__device__ __forceinline__ double rmt_tan(double x) { return tan(x); }
+__device__ __forceinline__ double rmt_tanh(double x) { return tanh(x); }
+__device__ __forceinline__ double rmt_sinh(double x) { return sinh(x); }
+__device__ __forceinline__ double rmt_cosh(double x) { return cosh(x); }
+__device__ __forceinline__ double rmt_atan(double x) { return atan(x); }
+__device__ __forceinline__ double rmt_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double rmt_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float rmt_exp(float x) { return expf(x); }
+__device__ __forceinline__ float rmt_exp10(float x) { return exp10f(x); }
+__device__ __forceinline__ float rmt_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float rmt_expm1(float x) { return expm1f(x); }
+__device__ __forceinline__ float rmt_log(float x) { return logf(x); }
+__device__ __forceinline__ float rmt_log10(float x) { return log10f(x); }
+__device__ __forceinline__ float rmt_log2(float x) { return log2f(x); }
+__device__ __forceinline__ float rmt_log1p(float x) { return log1pf(x); }
+__device__ __forceinline__ float rmt_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ float rmt_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ float rmt_pow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ float rmt_sin(float x) { return sinf(x); }
+__device__ __forceinline__ float rmt_cos(float x) { return cosf(x); }
+__device__ __forceinline__ float rmt_tan(float x) { return tanf(x); }
+__device__ __forceinline__ float rmt_tanh(float x) { return tanhf(x); }
+__device__ __forceinline__ float rmt_sinh(float x) { return sinhf(x); }
+__device__ __forceinline__ float rmt_cosh(float x) { return coshf(x); }
+__device__ __forceinline__ float rmt_atan(float x) { return atanf(x); }
+__device__ __forceinline__ float rmt_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float rmt_max(float a, float b) { return fmaxf(a, b); }
+
+template <typename T>
+__device__ __forceinline__ unsigned rmt_pow_flags(T x, T y) {
+    unsigned f = 0u;
+    if (x < T(0) && y != trunc(y)) f |= RMT_FLAG_DOMAIN;
+    if (x == T(0) && y < T(0)) f |= RMT_FLAG_DIV0;
+    return f;
+}
+
+RMT_KINETICS_SOURCE
+
+// ------------------------------------------------------------------ per-member constants
+struct RmtMember {
+    real cmax, tf, theta_in, rho_k, inv_cp0, f1, ft, inv_dz, inv_macote, inv_hecote, ua, tm;
+    preal p0, alpha_k, beta;
+    real cin[RMT_S];
+};
+
+__device__ __forceinline__ void rmt_load_member(const double* __restrict__ row, RmtMember& m) {
+    m.cmax = real(row[M_CMAX]);
+    m.tf = real(row[M_TF]);
+    m.theta_in = real(row[M_THETA_IN]);
+    m.rho_k = real(row[M_RHO_K]);
+    m.inv_cp0 = real(row[M_INV_CP0]);
+    m.f1 = real(row[M_F1]);
+    m.ft = real(row[M_FT]);
+    m.inv_dz = real(row[M_INV_DZ]);
+    m.inv_macote = real(row[M_INV_MACOTE]);
+    m.inv_hecote = real(row[M_INV_HECOTE]);
+    m.ua = real(row[M_UA]);
+    m.tm = real(row[M_TM]);
+    m.p0 = row[M_P0];
+    m.alpha_k = row[M_ALPHA_K];
+    m.beta = row[M_BETA];
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) m.cin[i] = real(row[M_CIN + i]);
+}
+
+// ------------------------------------------------------------------ node physics
+// Phase A (before the pressure scan): clamp, real concentrations, mole fractions, T, mixture MW,
+// Ergun affine coefficient.  pbHomoReactor.py:3897-3928, 3960-3979.
+struct RmtNode {
+    real x[RMT_S];
+    real C[RMT_S];
+    real T, M;
+};
+
+__device__ __forceinline__ preal rmt_node_pre(const RmtMember& m, const real* __restrict__ ys,
+                                              RmtNode& nd) {
+    real ctot = real(0);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) {
+        const real cc = rmt_max(ys[i], RMT_EPS);          // :3899
+        nd.C[i] = cc * m.cmax;                            // :3903 (MAX scaling)
+        ctot += nd.C[i];
+    }
+    const real inv_ctot = real(1) / ctot;
+    real mw = real(0);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) {
+        nd.x[i] = nd.C[i] * inv_ctot;                     // :3927
+        mw += nd.x[i] * RMT_MW[i];
+    }
+    nd.M = mw * real(1e-3);                               // :3960  [kg/mol]
+#if RMT_ISO
+    nd.T = m.tf;
+#else
+    nd.T = ys[RMT_S] * m.tf + m.tf;                       // :3914
+#endif
+    // P[z+1] = P[z] + dz*(-(ergA*ergB + 1.75*rho*v^2/dp*ergD)),  rho = P*M/(R*T)   (:3964-3979)
+    return preal(1) - m.alpha_k * (preal(nd.M) / preal(nd.T));
+}
+
+// Phase B (pressure known): kinetics, species source, Cp, heat of reaction, wall exchange,
+// upwind balances.  pbHomoReactor.py:3989-4128.  `up` = clamped state of node z-1 (or inlet).
+__device__ __forceinline__ void rmt_node_post(const RmtMember& m, const RmtNode& nd,
+                                              const real* __restrict__ ys,
+                                              const real* __restrict__ up, const preal Pz,
+                                              real* __restrict__ k, unsigned& flag) {
+    const real P = real(Pz);
+    real r[RMT_R];
+    rmt_kinetics(nd.T, P, nd.x, nd.C, r, flag);           // :3989-3992
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) {
+        real s = real(0);
+#pragma unroll
+        for (int q = 0; q < RMT_R; ++q) s += RMT_NU[q][i] * r[q];       // :4000
+        const real dcdz = (ys[i] - up[i]) * m.inv_dz;                   // :4086-4095
+        k[i] = m.f1 * (s * m.inv_macote - dcdz);                        // :4098
+    }
+#if !RMT_ISO
+    const real T = nd.T;
+    real cpbar[RMT_S];
+    real cpm = real(0);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) {
+        const real cpT = RMT_CP[i][0] + RMT_CP[i][1] * T + RMT_CP[i][2] * (T * T)
+                       + RMT_CP[i][3] * (T * T * T);
+        cpbar[i] = (RMT_CPREF[i] + cpT) * real(0.5);                    // rmtThermo.py:52-75
+        cpm += nd.x[i] * cpbar[i];                                      // :4013
+    }
+    real qr = real(0);
+#pragma unroll
+    for (int q = 0; q < RMT_R; ++q) {
+        real dcp = real(0);
+#pragma unroll
+        for (int i = 0; i < RMT_S; ++i) dcp += RMT_NU[q][i] * cpbar[i];
+        qr += r[q] * (dcp * (T - RMT_TREF) + RMT_DH25[q]);              // :4025-4032
+    }
+    const real qm = (m.tm == real(0)) ? real(0) : m.ua * (m.tm - T);    // rmtUtility.py:438-445
+    const real rho_s = (P * nd.M / T) * m.rho_k;                        // :3964-3966
+    const real cp_s = cpm * m.inv_cp0;                                  // :4016
+    const real dtdz = (ys[RMT_S] - up[RMT_S]) * m.inv_dz;               // :4104-4114
+    k[RMT_S] = m.f1 * ((qm - qr) * m.inv_hecote) / (rho_s * cp_s) - m.ft * dtdz;   // :4116-4126
+#endif
+}
+
+#ifndef RMT_HOST_EMULATION
+// ------------------------------------------------------------------ affine maps P -> a*P + b
+struct RmtAff { preal a, b; };
+__device__ __forceinline__ RmtAff rmt_then(const RmtAff first, const RmtAff second) {
+    RmtAff o;
+    o.a = second.a * first.a;
+    o.b = second.a * first.b + second.b;
+    return o;
+}
+
+struct RmtShared {
+    preal tot_a[2][RMT_NW];
+    preal tot_b[2][RMT_NW];
+    real bnd[2][RMT_NW][RMT_V];
+    real red[2][RMT_NW];
+};
+
+struct RmtCarry {       // workgroup-uniform hand-over between consecutive node blocks
+    preal P;            // pressure at the first node of the block
+    real up[RMT_V];     // clamped state of the node just upstream of the block (inlet for block 0)
+};
+
+__device__ __forceinline__ void rmt_carry_inlet(const RmtMember& m, RmtCarry& c) {
+    c.P = m.p0;
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) c.up[i] = m.cin[i];                 // :4090
+#if !RMT_ISO
+    c.up[RMT_S] = m.theta_in;                                           // :4108
+#endif
+}
+
+// RHS for the NPT consecutive nodes owned by this thread (nodes base+tid*NPT ...).
+// `nvalid` = how many of them exist (< NPT only at the reactor's end).  One __syncthreads().
+// buf = LDS ping-pong index; callers alternate it between consecutive calls.
+template <int NPT, bool CARRY_OUT>
+__device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh, const int buf,
+                                              const real (&ys)[NPT][RMT_V], const int nvalid,
+                                              RmtCarry& carry, real (&k)[NPT][RMT_V],
+                                              unsigned& flag) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    RmtNode nd[NPT];
+    RmtAff loc[NPT];
+    RmtAff mine = {preal(1), preal(0)};
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const preal a = rmt_node_pre(m, ys[j], nd[j]);
+        loc[j].a = (j < nvalid) ? a : preal(1);
+        loc[j].b = (j < nvalid) ? m.beta : preal(0);
+        mine = rmt_then(mine, loc[j]);
+    }
+    // inclusive Kogge-Stone scan of the per-lane maps over the wave
+    RmtAff inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        RmtAff prev;
+        prev.a = __shfl_up(inc.a, d);
+        prev.b = __shfl_up(inc.b, d);
+        if (lane >= d) inc = rmt_then(prev, inc);
+    }
+    // clamped state of my last node, for my downstream neighbour
+    real last[RMT_V];
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) last[i] = rmt_max(ys[NPT - 1][i], RMT_EPS);      // :4093
+#if !RMT_ISO
+    last[RMT_S] = ys[NPT - 1][RMT_S];                                                // :4111
+#endif
+    if (lane == 63) {
+        sh.tot_a[buf][wave] = inc.a;
+        sh.tot_b[buf][wave] = inc.b;
+#pragma unroll
+        for (int i = 0; i < RMT_V; ++i) sh.bnd[buf][wave][i] = last[i];
+    }
+    RmtAff exc;
+    exc.a = __shfl_up(inc.a, 1);
+    exc.b = __shfl_up(inc.b, 1);
+    if (lane == 0) { exc.a = preal(1); exc.b = preal(0); }
+    real up[RMT_V];
+#pragma unroll
+    for (int i = 0; i < RMT_V; ++i) up[i] = __shfl_up(last[i], 1);
+    __syncthreads();
+    // pressure entering this wave = carry.P pushed through the totals of the waves before it
+    preal pw = carry.P;
+    for (int w = 0; w < wave; ++w) pw = sh.tot_a[buf][w] * pw + sh.tot_b[buf][w];
+    if (lane == 0) {
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) up[i] = carry.up[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) up[i] = sh.bnd[buf][wave - 1][i];
+        }
+    }
+    preal P = exc.a * pw + exc.b;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        unsigned f = 0u;
+        rmt_node_post(m, nd[j], ys[j], up, P, k[j], f);
+        if (j < nvalid) flag |= f;
+        P = loc[j].a * P + loc[j].b;
+        if (j + 1 < NPT) {
+#pragma unroll
+            for (int i = 0; i < RMT_S; ++i) up[i] = rmt_max(ys[j][i], RMT_EPS);
+#if !RMT_ISO
+            up[RMT_S] = ys[j][RMT_S];
+#endif
+        }
+    }
+    if (CARRY_OUT) {
+        preal pe = pw;
+        for (int w = wave; w < RMT_NW; ++w) pe = sh.tot_a[buf][w] * pe + sh.tot_b[buf][w];
+        carry.P = pe;
+#pragma unroll
+        for (int i = 0; i < RMT_V; ++i) carry.up[i] = sh.bnd[buf][RMT_NW - 1][i];
+    }
+}
+
+// ------------------------------------------------------------------ helpers for the kernels
+__device__ __forceinline__ void rmt_safe_state(const RmtMember& m, real* __restrict__ v) {
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) v[i] = m.cin[i];
+#if !RMT_ISO
+    v[RMT_S] = m.theta_in;
+#endif
+}
+
+__device__ __forceinline__ unsigned rmt_finite_flag(const real* __restrict__ v) {
+    unsigned f = 0u;
+#pragma unroll
+    for (int i = 0; i < RMT_V; ++i) f |= (v[i] - v[i] == real(0)) ? 0u : RMT_FLAG_NONFINITE;
+    return f;
+}
+
+// ===================================================================== kernel: one RHS evaluation
+// dydt[e] = f(y[e]) for every reactor e = blockIdx.x; any N (blocks of RMT_BLOCK nodes, carry
+// handed from block to block).  Replaces one call of modelEquationN2 (pbHomoReactor.py:3706).
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rhs(
+        const real* __restrict__ y, real* __restrict__ dydt, const double* __restrict__ members,
+        const int N, unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+    const int e = blockIdx.x;
+    RmtMember m;
+    rmt_load_member(members + (size_t)e * RMT_NM, m);
+    RmtCarry carry;
+    rmt_carry_inlet(m, carry);
+    const real* ye = y + (size_t)e * RMT_V * N;
+    real* de = dydt + (size_t)e * RMT_V * N;
+    unsigned flag = 0u;
+    int ph = 0;
+    for (int base = 0; base < N; base += RMT_BLOCK, ph ^= 1) {
+        const int node = base + (int)threadIdx.x;
+        const bool valid = node < N;
+        real ys[1][RMT_V], k[1][RMT_V];
+        rmt_safe_state(m, ys[0]);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) ys[0][i] = ye[(size_t)i * N + node];
+        }
+        rmt_rhs_block<1, true>(m, sh, ph, ys, valid ? 1 : 0, carry, k, flag);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) de[(size_t)i * N + node] = k[0][i];
+            flag |= rmt_finite_flag(k[0]);
+        }
+    }
+    if (flag) atomicOr(&flags[e], flag);
+}
+
+// ===================================================================== kernel: RK4, state in registers
+// nsteps classic RK4 steps of size h (tableau and update order of odeSolver.py:17-40) for reactor
+// e = blockIdx.x with N <= RMT_BLOCK*RMT_NPT nodes.  The state is read once, kept in VGPRs for
+// all steps, and written once: HBM traffic is 2*V*sizeof(real) per node per LAUNCH.
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
+        real* __restrict__ y, const double* __restrict__ members, const int N, const double h_,
+        const long long nsteps, unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+    const int e = blockIdx.x;
+    RmtMember m;
+    rmt_load_member(members + (size_t)e * RMT_NM, m);
+    RmtCarry carry;
+    rmt_carry_inlet(m, carry);
+    real* ye = y + (size_t)e * RMT_V * N;
+    const int node0 = (int)threadIdx.x * RMT_NPT;
+    int nvalid = N - node0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > RMT_NPT ? RMT_NPT : nvalid);
+    real y0[RMT_NPT][RMT_V], ys[RMT_NPT][RMT_V], acc[RMT_NPT][RMT_V], k[RMT_NPT][RMT_V];
+#pragma unroll
+    for (int j = 0; j < RMT_NPT; ++j) {
+        rmt_safe_state(m, y0[j]);
+        if (j < nvalid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) y0[j][i] = ye[(size_t)i * N + node0 + j];
+        }
+    }
+    const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
+    unsigned flag = 0u;
+    for (long long step = 0; step < nsteps; ++step) {
+        rmt_rhs_block<RMT_NPT, false>(m, sh, 0, y0, nvalid, carry, k, flag);          // K1 = f(y)
+#pragma unroll
+        for (int j = 0; j < RMT_NPT; ++j)
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) { acc[j][i] = k[j][i]; ys[j][i] = y0[j][i] + k[j][i] * hh; }
+        rmt_rhs_block<RMT_NPT, false>(m, sh, 1, ys, nvalid, carry, k, flag);          // K2 = f(y+K1 h/2)
+#pragma unroll
+        for (int j = 0; j < RMT_NPT; ++j)
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) { acc[j][i] += real(2) * k[j][i]; ys[j][i] = y0[j][i] + k[j][i] * hh; }
+        rmt_rhs_block<RMT_NPT, false>(m, sh, 0, ys, nvalid, carry, k, flag);          // K3 = f(y+K2 h/2)
+#pragma unroll
+        for (int j = 0; j < RMT_NPT; ++j)
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) { acc[j][i] += real(2) * k[j][i]; ys[j][i] = y0[j][i] + k[j][i] * h; }
+        rmt_rhs_block<RMT_NPT, false>(m, sh, 1, ys, nvalid, carry, k, flag);          // K4 = f(y+K3 h)
+#pragma unroll
+        for (int j = 0; j < RMT_NPT; ++j)
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) y0[j][i] += h6 * (acc[j][i] + k[j][i]);   // y + h(K1+2K2+2K3+K4)/6
+    }
+#pragma unroll
+    for (int j = 0; j < RMT_NPT; ++j) {
+        if (j < nvalid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) ye[(size_t)i * N + node0 + j] = y0[j][i];
+            flag |= rmt_finite_flag(y0[j]);
+        }
+    }
+    if (flag) atomicOr(&flags[e], flag);
+}
+
+// ===================================================================== kernel: RK4, state in memory
+// Same integrator for any N: the workgroup walks its reactor in blocks of RMT_BLOCK nodes per stage.
+// work = 3 arrays [E][V][N]: stage state A, stage state B, K accumulator.  Every thread only ever
+// touches its own nodes' entries, so no global-memory synchronisation is needed.
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_mem(
+        real* __restrict__ y, real* __restrict__ work, const double* __restrict__ members,
+        const int N, const int E, const double h_, const long long nsteps,
+        unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+    const int e = blockIdx.x;
+    RmtMember m;
+    rmt_load_member(members + (size_t)e * RMT_NM, m);
+    const size_t per = (size_t)RMT_V * N, tot = per * E;
+    real* ye = y + e * per;
+    real* wa = work + e * per;
+    real* wb = work + tot + e * per;
+    real* wacc = work + 2 * tot + e * per;
+    const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
+    unsigned flag = 0u;
+    int ph = 0;
+    for (long long step = 0; step < nsteps; ++step) {
+#pragma unroll 1
+        for (int s = 0; s < 4; ++s) {
+            const real* src = (s == 0) ? ye : ((s == 2) ? wb : wa);
+            real* dst = (s == 1) ? wb : wa;
+            const real cn = (s == 2) ? h : hh;
+            const real wk = (s == 1 || s == 2) ? real(2) : real(1);
+            RmtCarry carry;
+            rmt_carry_inlet(m, carry);
+            for (int base = 0; base < N; base += RMT_BLOCK, ph ^= 1) {
+                const int node = base + (int)threadIdx.x;
+                const bool valid = node < N;
+                real ys[1][RMT_V], k[1][RMT_V];
+                rmt_safe_state(m, ys[0]);
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V; ++i) ys[0][i] = src[(size_t)i * N + node];
+                }
+                rmt_rhs_block<1, true>(m, sh, ph, ys, valid ? 1 : 0, carry, k, flag);
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V; ++i) {
+                        const size_t o = (size_t)i * N + node;
+                        const real a = (s == 0) ? k[0][i] : wacc[o] + wk * k[0][i];
+                        if (s < 3) {
+                            wacc[o] = a;
+                            dst[o] = ye[o] + k[0][i] * cn;
+                        } else {
+                            const real yn = ye[o] + h6 * a;
+                            ye[o] = yn;
+                            flag |= (yn - yn == real(0)) ? 0u : RMT_FLAG_NONFINITE;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (flag) atomicOr(&flags[e], flag);
+}
+#endif  // RMT_HOST_EMULATION
+)RMTSRC"

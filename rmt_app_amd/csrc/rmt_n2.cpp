@@ -1,0 +1,288 @@
+// C-ABI host side of the MI355X N2 integrator (see include/rmt_n2.h for the contract and the
+// reference interfaces each entry point replaces).  Host code only: the device code is the
+// template in n2_kernels.inc, specialised by a generated prelude and compiled with hipRTC.
+#include "rmt_n2.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static const char* const k_template =
+#include "n2_kernels_embed.h"
+    ;
+
+static thread_local std::string g_err;
+
+static int fail(const char* fmt, ...) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_OK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return fail("%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct rmt_n2_handle {
+    int S = 0, V = 0, N = 0, E = 0, fp32 = 0, block = 0, npt = 0, mode = 0, device = 0;
+    size_t real_size = 8;
+    hipModule_t module = nullptr;
+    hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
+                  f_rk45_mem = nullptr;
+    double* d_members = nullptr;
+    unsigned* d_flags = nullptr;
+    void* d_work = nullptr;
+    size_t work_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+};
+
+extern "C" const char* rmt_n2_last_error(void) { return g_err.c_str(); }
+extern "C" int rmt_n2_abi_version(void) { return RMT_N2_ABI_VERSION; }
+extern "C" const char* rmt_n2_kernel_template(void) { return k_template; }
+extern "C" void rmt_n2_free(void* p) { free(p); }
+
+extern "C" int rmt_n2_compile(const char* source, const char* arch, const char* extra_opts,
+                              void** code, size_t* code_size, char** log) {
+    if (!source || !code || !code_size) return fail("rmt_n2_compile: null argument");
+    *code = nullptr;
+    *code_size = 0;
+    if (log) *log = nullptr;
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, source, "rmt_n2_generated.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    std::string archopt = std::string("--offload-arch=") + (arch && *arch ? arch : "gfx950");
+    std::vector<std::string> store = {archopt, "-O3", "-std=c++17"};
+    if (extra_opts && *extra_opts) {
+        std::string s(extra_opts);
+        size_t pos = 0;
+        while (pos < s.size()) {
+            size_t sp = s.find(' ', pos);
+            if (sp == std::string::npos) sp = s.size();
+            if (sp > pos) store.push_back(s.substr(pos, sp - pos));
+            pos = sp + 1;
+        }
+    }
+    std::vector<const char*> opts;
+    for (auto& s : store) opts.push_back(s.c_str());
+    r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
+    size_t logsz = 0;
+    hiprtcGetProgramLogSize(prog, &logsz);
+    std::string logs(logsz, '\0');
+    if (logsz) hiprtcGetProgramLog(prog, &logs[0]);
+    if (log && logsz) {
+        *log = (char*)malloc(logsz + 1);
+        memcpy(*log, logs.c_str(), logsz);
+        (*log)[logsz] = 0;
+    }
+    if (r != HIPRTC_SUCCESS) {
+        hiprtcDestroyProgram(&prog);
+        return fail("hiprtcCompileProgram: %s\n%.1500s", hiprtcGetErrorString(r), logs.c_str());
+    }
+    size_t sz = 0;
+    hiprtcGetCodeSize(prog, &sz);
+    void* buf = malloc(sz);
+    if (!buf) {
+        hiprtcDestroyProgram(&prog);
+        return fail("out of host memory for %zu byte code object", sz);
+    }
+    hiprtcGetCode(prog, (char*)buf);
+    hiprtcDestroyProgram(&prog);
+    *code = buf;
+    *code_size = sz;
+    return 0;
+}
+
+extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
+    if (!p || !out) return fail("rmt_n2_create: null argument");
+    *out = nullptr;
+    if (p->abi_version != RMT_N2_ABI_VERSION)
+        return fail("ABI version mismatch: plan %d, library %d", p->abi_version, RMT_N2_ABI_VERSION);
+    if (p->n_species < 1 || p->n_nodes < 2 || p->n_members < 1)
+        return fail("bad plan sizes S=%d N=%d E=%d", p->n_species, p->n_nodes, p->n_members);
+    if (p->n_vars != p->n_species && p->n_vars != p->n_species + 1)
+        return fail("n_vars must be S or S+1 (got %d for S=%d)", p->n_vars, p->n_species);
+    if (p->block < 64 || p->block > 1024 || p->block % 64)
+        return fail("block must be a multiple of 64 in [64,1024] (got %d)", p->block);
+    if (p->nodes_per_thread < 1) return fail("nodes_per_thread must be >= 1");
+    if (!p->code_object || !p->code_size || !p->members) return fail("plan lacks code object/members");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail("no HIP device available: the N2 integrator has no CPU fallback");
+    rmt_n2_handle* h = new rmt_n2_handle();
+    h->S = p->n_species;
+    h->V = p->n_vars;
+    h->N = p->n_nodes;
+    h->E = p->n_members;
+    h->fp32 = p->fp32;
+    h->block = p->block;
+    h->npt = p->nodes_per_thread;
+    h->real_size = p->fp32 ? 4 : 8;
+#define CREATE_OK(call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            fail("%s failed: %s", #call, hipGetErrorString(e_));                            \
+            rmt_n2_destroy(h);                                                              \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+    CREATE_OK(hipGetDevice(&h->device));
+    CREATE_OK(hipModuleLoadData(&h->module, p->code_object));
+    CREATE_OK(hipModuleGetFunction(&h->f_rhs, h->module, "rmt_n2_rhs"));
+    CREATE_OK(hipModuleGetFunction(&h->f_rk4_reg, h->module, "rmt_n2_rk4_reg"));
+    CREATE_OK(hipModuleGetFunction(&h->f_rk4_mem, h->module, "rmt_n2_rk4_mem"));
+    if (hipModuleGetFunction(&h->f_rk45_reg, h->module, "rmt_n2_rk45_reg") != hipSuccess)
+        h->f_rk45_reg = nullptr;
+    if (hipModuleGetFunction(&h->f_rk45_mem, h->module, "rmt_n2_rk45_mem") != hipSuccess)
+        h->f_rk45_mem = nullptr;
+    (void)hipGetLastError();
+    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
+    CREATE_OK(hipMalloc((void**)&h->d_members, mbytes));
+    CREATE_OK(hipMemcpy(h->d_members, p->members, mbytes, hipMemcpyHostToDevice));
+    CREATE_OK(hipMalloc((void**)&h->d_flags, (size_t)h->E * sizeof(unsigned)));
+    CREATE_OK(hipMemset(h->d_flags, 0, (size_t)h->E * sizeof(unsigned)));
+    CREATE_OK(hipEventCreate(&h->ev0));
+    CREATE_OK(hipEventCreate(&h->ev1));
+#undef CREATE_OK
+    *out = h;
+    return 0;
+}
+
+extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
+    if (!h) return;
+    if (h->d_members) (void)hipFree(h->d_members);
+    if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->d_work) (void)hipFree(h->d_work);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->module) (void)hipModuleUnload(h->module);
+    delete h;
+}
+
+extern "C" int rmt_n2_set_stream(rmt_n2_handle* h, void* s) {
+    if (!h) return fail("null handle");
+    h->stream = (hipStream_t)s;
+    return 0;
+}
+
+extern "C" int rmt_n2_set_mode(rmt_n2_handle* h, int mode) {
+    if (!h) return fail("null handle");
+    if (mode < 0 || mode > 2) return fail("mode must be 0 (auto), 1 (registers) or 2 (memory)");
+    h->mode = mode;
+    return 0;
+}
+
+extern "C" int rmt_n2_set_members(rmt_n2_handle* h, const double* members) {
+    if (!h || !members) return fail("null argument");
+    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
+    HIP_OK(hipMemcpyAsync(h->d_members, members, mbytes, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int ensure_work(rmt_n2_handle* h, size_t arrays) {
+    const size_t need = arrays * (size_t)h->E * h->V * h->N * h->real_size;
+    if (h->work_bytes >= need) return 0;
+    if (h->d_work) {
+        HIP_OK(hipStreamSynchronize(h->stream));
+        HIP_OK(hipFree(h->d_work));
+        h->d_work = nullptr;
+        h->work_bytes = 0;
+    }
+    HIP_OK(hipMalloc(&h->d_work, need));
+    h->work_bytes = need;
+    return 0;
+}
+
+static int launch(rmt_n2_handle* h, hipFunction_t f, void** args) {
+    HIP_OK(hipEventRecord(h->ev0, h->stream));
+    HIP_OK(hipModuleLaunchKernel(f, (unsigned)h->E, 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args,
+                                 nullptr));
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
+}
+
+extern "C" int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms) {
+    if (!h || !ms) return fail("null argument");
+    if (!h->timed) return fail("no launch recorded yet");
+    HIP_OK(hipEventSynchronize(h->ev1));
+    HIP_OK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+extern "C" int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt) {
+    (void)t; /* the N2 right-hand side is autonomous (pbHomoReactor.py:3706: t unused) */
+    if (!h || !y || !dydt) return fail("null argument");
+    int N = h->N;
+    void* args[] = {(void*)&y, (void*)&dydt, (void*)&h->d_members, (void*)&N, (void*)&h->d_flags};
+    return launch(h, h->f_rhs, args);
+}
+
+static bool fits_registers(const rmt_n2_handle* h) { return h->N <= h->block * h->npt; }
+
+extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64_t nsteps) {
+    (void)t0;
+    if (!h || !y) return fail("null argument");
+    if (!(dt > 0) || nsteps < 0) return fail("rk4 needs dt > 0 and nsteps >= 0");
+    int N = h->N, E = h->E;
+    long long ns = (long long)nsteps;
+    const bool reg = h->mode == 1 || (h->mode == 0 && fits_registers(h));
+    if (reg) {
+        if (!fits_registers(h))
+            return fail("register-resident stepper holds at most %d nodes per reactor (N=%d)",
+                        h->block * h->npt, h->N);
+        void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&dt, (void*)&ns,
+                        (void*)&h->d_flags};
+        return launch(h, h->f_rk4_reg, args);
+    }
+    if (ensure_work(h, 3)) return 1;
+    void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,
+                    (void*)&dt, (void*)&ns, (void*)&h->d_flags};
+    return launch(h, h->f_rk4_mem, args);
+}
+
+extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, double rtol, double atol,
+                           double h0, int64_t max_steps, rmt_n2_stats* stats) {
+    if (!h || !y || !stats) return fail("null argument");
+    if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad rk45 arguments");
+    int N = h->N, E = h->E;
+    long long ms = (long long)max_steps;
+    const bool reg = (h->mode == 1 || (h->mode == 0 && fits_registers(h))) && h->f_rk45_reg;
+    if (reg) {
+        if (!fits_registers(h)) return fail("register-resident rk45 does not fit N=%d", h->N);
+        void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&t0, (void*)&t1,
+                        (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms, (void*)&stats,
+                        (void*)&h->d_flags};
+        return launch(h, h->f_rk45_reg, args);
+    }
+    if (!h->f_rk45_mem) return fail("code object has no rk45 kernel");
+    if (ensure_work(h, 8)) return 1;
+    void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,
+                    (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms,
+                    (void*)&stats, (void*)&h->d_flags};
+    return launch(h, h->f_rk45_mem, args);
+}
+
+extern "C" int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host) {
+    if (!h || !flags_host) return fail("null argument");
+    HIP_OK(hipMemcpyAsync(flags_host, h->d_flags, (size_t)h->E * sizeof(unsigned), hipMemcpyDeviceToHost,
+                          h->stream));
+    HIP_OK(hipMemsetAsync(h->d_flags, 0, (size_t)h->E * sizeof(unsigned), h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}

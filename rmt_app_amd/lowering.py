@@ -1,0 +1,529 @@
+"""Lowering of PyREMOT ``reaction-rates`` lambdas to a HIP device function.
+
+The reference evaluates the user's VARS / RATES dicts node by node in Python
+(reactionRateExe, PyREMOT/docs/rmtReaction.py:11-61): VARS entries are evaluated in insertion
+order into one namespace that already holds ``R_CONST, T, P, MoFri, SpCoi``; entries that are
+functions are called with the partially filled namespace, everything else is copied as a
+constant; then every RATES lambda is called with the full namespace.
+
+Here the same ordered evaluation is performed ONCE, symbolically: each lambda is rebuilt with
+its ``math`` / ``numpy`` globals (and closure cells) replaced by tracing shims and is called on
+a namespace of symbols.  The result is an expression DAG over ``T, P, MoFri[i], SpCoi[i]`` with
+hash-consed common subexpressions and folded constants, which is printed as straight-line HIP
+C++ (one ``const real vN = ...;`` per node) for the fused RHS kernel.
+
+Python raises on ``log(<=0)``, ``sqrt(<0)``, ``x/0``, ``exp`` overflow and ``pow`` domain
+errors; the generated code sets bits of a per-reactor status word instead (see FLAG_*), which
+the host turns back into the matching Python exception.
+
+Constructs that cannot be traced (data-dependent ``if``, calls into C extensions other than
+math/numpy elementwise functions, ...) raise ``LoweringError`` - there is no CPU fallback.
+"""
+import hashlib
+import math
+import types
+
+import numpy as np
+
+FLAG_DOMAIN = 1       # math domain error   (log/sqrt/pow of a bad argument)
+FLAG_DIV0 = 2         # float division by zero
+FLAG_OVERFLOW = 4     # math range error    (exp/pow overflow)
+FLAG_NONFINITE = 8    # a derivative came out NaN/Inf without one of the above
+FLAG_STEP = 16        # adaptive step size underflow (rk45)
+
+_EXP_MAX = 709.782712893384  # math.exp raises OverflowError above this
+
+
+class LoweringError(Exception):
+    pass
+
+
+class Graph:
+    """Hash-consed expression DAG.  Node = (op, a, b); ids are creation-ordered (topological)."""
+
+    def __init__(self):
+        self.nodes = []
+        self._index = {}
+
+    def _mk(self, op, a=None, b=None):
+        key = (op, a, b)
+        i = self._index.get(key)
+        if i is None:
+            i = len(self.nodes)
+            self.nodes.append(key)
+            self._index[key] = i
+        return Sym(self, i)
+
+    def const(self, v):
+        v = float(v)
+        return self._mk("const", v.hex() if math.isfinite(v) else repr(v))
+
+    def inp(self, name):
+        return self._mk("in", name)
+
+    def is_const(self, i):
+        return self.nodes[i][0] == "const"
+
+    def cval(self, i):
+        s = self.nodes[i][1]
+        return float.fromhex(s) if s not in ("inf", "-inf", "nan") else float(s)
+
+
+def _num(v):
+    return isinstance(v, (int, float, np.floating, np.integer)) and not isinstance(v, bool)
+
+
+class Sym:
+    __slots__ = ("g", "i")
+    __array_priority__ = 1000
+
+    def __init__(self, g, i):
+        self.g, self.i = g, i
+
+    # ---- helpers
+    def _lift(self, o):
+        if isinstance(o, Sym):
+            return o
+        if _num(o) or isinstance(o, bool):
+            return self.g.const(float(o))
+        if isinstance(o, np.ndarray) and o.ndim == 0:
+            return self.g.const(float(o))
+        raise LoweringError("cannot combine a traced value with %r" % (type(o),))
+
+    def _bin(self, op, a, b, pyop):
+        g = self.g
+        if g.is_const(a.i) and g.is_const(b.i):
+            try:
+                return g.const(pyop(g.cval(a.i), g.cval(b.i)))
+            except (ZeroDivisionError, OverflowError, ValueError):
+                pass  # keep it symbolic: the device flags it at run time like Python would raise
+        if op in ("add", "mul") and a.i > b.i:      # canonical order for commutative ops
+            a, b = b, a
+        return g._mk(op, a.i, b.i)
+
+    def _un(self, op, pyfn):
+        g = self.g
+        if g.is_const(self.i):
+            try:
+                return g.const(pyfn(g.cval(self.i)))
+            except (ZeroDivisionError, OverflowError, ValueError):
+                pass
+        return g._mk(op, self.i)
+
+    # ---- arithmetic
+    def __add__(self, o): return self._bin("add", self, self._lift(o), lambda a, b: a + b)
+    def __radd__(self, o): return self._bin("add", self._lift(o), self, lambda a, b: a + b)
+    def __sub__(self, o): return self._bin("sub", self, self._lift(o), lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin("sub", self._lift(o), self, lambda a, b: a - b)
+    def __mul__(self, o): return self._bin("mul", self, self._lift(o), lambda a, b: a*b)
+    def __rmul__(self, o): return self._bin("mul", self._lift(o), self, lambda a, b: a*b)
+    def __truediv__(self, o): return self._bin("div", self, self._lift(o), lambda a, b: a/b)
+    def __rtruediv__(self, o): return self._bin("div", self._lift(o), self, lambda a, b: a/b)
+    def __neg__(self): return self._un("neg", lambda a: -a)
+    def __pos__(self): return self
+    def __abs__(self): return self._un("abs", abs)
+    def __pow__(self, o): return _pow(self, self._lift(o))
+    def __rpow__(self, o): return _pow(self._lift(o), self)
+
+    # ---- things a trace cannot follow
+    def __bool__(self):
+        raise LoweringError("data-dependent branching on a traced value is not supported")
+
+    def _cmp(self, o):
+        raise LoweringError("comparisons of traced values are not supported (use math-only "
+                            "rate expressions, or max/min via numpy.maximum/minimum)")
+    __lt__ = __le__ = __gt__ = __ge__ = _cmp
+
+    def __float__(self):
+        if self.g.is_const(self.i):
+            return self.g.cval(self.i)
+        raise LoweringError("a traced value was passed to a function that needs a real number "
+                            "(a C function other than the math/numpy elementwise set?)")
+
+    __hash__ = object.__hash__
+
+
+def _pow(a, b):
+    g = a.g
+    if g.is_const(a.i) and g.is_const(b.i):
+        try:
+            return g.const(math.pow(g.cval(a.i), g.cval(b.i)))
+        except (ZeroDivisionError, OverflowError, ValueError):
+            pass
+    if g.is_const(b.i):
+        e = g.cval(b.i)
+        if e == 1.0:
+            return a
+        if e == 0.0:
+            return g.const(1.0)
+        if e == 0.5:
+            return a._un("sqrt", math.sqrt)
+        if float(e).is_integer() and abs(e) <= 16:
+            return g._mk("powi", a.i, int(e))
+    if g.is_const(a.i):
+        base = g.cval(a.i)
+        if base == 10.0:
+            return g._mk("exp10", b.i)
+        if base == 2.0:
+            return g._mk("exp2", b.i)
+        if base == math.e:
+            return g._mk("exp", b.i)
+    return g._mk("pow", a.i, b.i)
+
+
+class SymVector:
+    """MoFri / SpCoi: integer-indexable, iterable vector of input symbols."""
+
+    def __init__(self, syms):
+        self._s = list(syms)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return SymVector(self._s[k])
+        if isinstance(k, (int, np.integer)):
+            return self._s[int(k)]
+        raise LoweringError("only integer indexing of MoFri/SpCoi can be lowered")
+
+    def __len__(self):
+        return len(self._s)
+
+    def __iter__(self):
+        return iter(self._s)
+
+
+def _fn1(op, pyfn):
+    def f(x, *rest):
+        if rest:
+            raise LoweringError("%s() with extra arguments is not supported" % op)
+        if isinstance(x, Sym):
+            return x._un(op, pyfn)
+        return pyfn(x)
+    f.__name__ = op
+    return f
+
+
+class _ShimMath:
+    """Replacement for the ``math`` module (and the elementwise subset of numpy) while tracing."""
+    pi, e, inf, nan, tau = math.pi, math.e, math.inf, math.nan, math.tau
+    exp = staticmethod(_fn1("exp", math.exp))
+    log10 = staticmethod(_fn1("log10", math.log10))
+    log2 = staticmethod(_fn1("log2", math.log2))
+    sqrt = staticmethod(_fn1("sqrt", math.sqrt))
+    fabs = staticmethod(_fn1("abs", math.fabs))
+    abs = absolute = fabs
+    sin = staticmethod(_fn1("sin", math.sin))
+    cos = staticmethod(_fn1("cos", math.cos))
+    tan = staticmethod(_fn1("tan", math.tan))
+    tanh = staticmethod(_fn1("tanh", math.tanh))
+    sinh = staticmethod(_fn1("sinh", math.sinh))
+    cosh = staticmethod(_fn1("cosh", math.cosh))
+    atan = arctan = staticmethod(_fn1("atan", math.atan))
+    expm1 = staticmethod(_fn1("expm1", math.expm1))
+    log1p = staticmethod(_fn1("log1p", math.log1p))
+
+    @staticmethod
+    def log(x, base=None):
+        r = x._un("log", math.log) if isinstance(x, Sym) else math.log(x)
+        if base is None:
+            return r
+        lb = base._un("log", math.log) if isinstance(base, Sym) else math.log(base)
+        return r/lb
+
+    @staticmethod
+    def pow(x, y):
+        if isinstance(x, Sym):
+            return x**y
+        if isinstance(y, Sym):
+            return y.__rpow__(x)
+        return math.pow(x, y)
+    power = float_power = pow
+
+    @staticmethod
+    def maximum(a, b):
+        return _minmax("max", a, b)
+
+    @staticmethod
+    def minimum(a, b):
+        return _minmax("min", a, b)
+
+    @staticmethod
+    def sum(v):
+        tot = 0.0
+        for s in v:
+            tot = tot + s
+        return tot
+
+    @staticmethod
+    def array(v, *a, **k):
+        return SymVector(list(v)) if any(isinstance(s, Sym) for s in v) else np.array(v, *a, **k)
+
+    def __getattr__(self, name):
+        raise LoweringError("math/numpy function %r cannot be lowered to the device" % name)
+
+
+def _minmax(op, a, b):
+    s = a if isinstance(a, Sym) else b
+    if not isinstance(s, Sym):
+        return max(a, b) if op == "max" else min(a, b)
+    a, b = s._lift(a), s._lift(b)
+    return s.g._mk(op, min(a.i, b.i), max(a.i, b.i))
+
+
+_SHIM = _ShimMath()
+_MATH_NAMES = {n for n in dir(math) if not n.startswith("_")}
+
+
+def _shim_value(v, memo):
+    """Map a global / closure value to its tracing counterpart."""
+    if v is math or v is np:
+        return _SHIM
+    if isinstance(v, types.BuiltinFunctionType) and getattr(v, "__module__", None) == "math":
+        return getattr(_SHIM, v.__name__)
+    if isinstance(v, np.ufunc):
+        return getattr(_SHIM, v.__name__)
+    if isinstance(v, types.FunctionType):
+        return rebind(v, memo)
+    return v
+
+
+def rebind(fn, memo=None):
+    """Rebuild ``fn`` so that math / numpy references (globals and closure cells, recursively
+    through helper functions) resolve to the tracing shims."""
+    if memo is None:
+        memo = {}
+    if id(fn) in memo:
+        return memo[id(fn)]
+    mod = getattr(fn, "__module__", "") or ""
+    if mod == __name__:
+        return fn
+    if mod == "math" or mod.split(".")[0] == "numpy":
+        return getattr(_SHIM, fn.__name__)
+    memo[id(fn)] = fn                  # provisional entry: guards against reference cycles
+    names = set()
+    stack = [fn.__code__]
+    while stack:                       # names used by nested code objects too
+        co = stack.pop()
+        names.update(co.co_names)
+        stack.extend(c for c in co.co_consts if isinstance(c, types.CodeType))
+    g = {}
+    for k in names:
+        if k in fn.__globals__:
+            g[k] = _shim_value(fn.__globals__[k], memo)
+    g["__builtins__"] = fn.__globals__.get("__builtins__", __builtins__)
+    cells = None
+    if fn.__closure__:
+        cells = tuple(types.CellType(_shim_value(c.cell_contents, memo)) for c in fn.__closure__)
+    new = types.FunctionType(fn.__code__, g, fn.__name__, fn.__defaults__, cells)
+    new.__kwdefaults__ = fn.__kwdefaults__
+    for k, v in g.items():
+        if v is fn:
+            g[k] = new
+    memo[id(fn)] = new
+    return new
+
+
+class Lowered:
+    """Result of trace(): DAG + output node ids + op statistics."""
+
+    def __init__(self, graph, outputs, nspecies):
+        self.g, self.outputs, self.S = graph, outputs, nspecies
+        self.live = self._live()
+
+    def _live(self):
+        live, stack = set(), list(self.outputs)
+        while stack:
+            i = stack.pop()
+            if i in live:
+                continue
+            live.add(i)
+            op, a, b = self.g.nodes[i]
+            if op in ("const", "in"):
+                continue
+            stack.append(a)
+            if b is not None and op != "powi":
+                stack.append(b)
+        return live
+
+    def stats(self):
+        st = {}
+        for i in sorted(self.live):
+            op = self.g.nodes[i][0]
+            st[op] = st.get(op, 0) + 1
+        return st
+
+    def uses(self, name):
+        return any(self.g.nodes[i][:2] == ("in", name) for i in self.live)
+
+    def digest(self):
+        h = hashlib.sha256()
+        for i in sorted(self.live):
+            h.update(repr(self.g.nodes[i]).encode())
+        h.update(repr(self.outputs).encode())
+        return h.hexdigest()
+
+    # ---- evaluation on the host (used by tests to check the trace itself, not by the product path)
+    def evaluate(self, T, P, x, C):
+        env = {}
+        for i in sorted(self.live):
+            op, a, b = self.g.nodes[i]
+            if op == "const":
+                env[i] = self.g.cval(i)
+            elif op == "in":
+                env[i] = {"T": T, "P": P}.get(a) if a in ("T", "P") else (
+                    x[int(a[1:])] if a[0] == "x" else C[int(a[1:])])
+            elif op == "powi":
+                env[i] = env[a]**b
+            elif op in ("add", "sub", "mul", "div", "pow", "min", "max"):
+                u, v = env[a], env[b]
+                env[i] = {"add": lambda: u + v, "sub": lambda: u - v, "mul": lambda: u*v,
+                          "div": lambda: u/v, "pow": lambda: math.pow(u, v),
+                          "min": lambda: min(u, v), "max": lambda: max(u, v)}[op]()
+            else:
+                fn = {"neg": lambda u: -u, "abs": abs, "exp10": lambda u: 10.0**u,
+                      "exp2": lambda u: 2.0**u}.get(op) or getattr(math, op)
+                env[i] = fn(env[a])
+        return [env[o] for o in self.outputs]
+
+    # ---- HIP C++ emission
+    def emit(self, fname="rmt_kinetics"):
+        g = self.g
+        lines = []
+        name = {}
+        seen_checks = set()
+
+        def lit(v):
+            if math.isnan(v):
+                return "real(NAN)"
+            if math.isinf(v):
+                return "real(INFINITY)" if v > 0 else "real(-INFINITY)"
+            r = repr(float(v))
+            return "real(%s)" % r
+
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op == "const":
+                name[i] = lit(g.cval(i))
+                continue
+            if op == "in":
+                name[i] = a if a in ("T", "P") else ("x[%s]" % a[1:] if a[0] == "x" else "C[%s]" % a[1:])
+                continue
+            v = "v%d" % i
+            A = name[a]
+            B = name[b] if (b is not None and op != "powi") else None
+            pre = []
+            if op == "add":
+                e = "%s + %s" % (A, B)
+            elif op == "sub":
+                e = "%s - %s" % (A, B)
+            elif op == "mul":
+                e = "%s * %s" % (A, B)
+            elif op == "div":
+                pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (B, FLAG_DIV0))
+                e = "%s / %s" % (A, B)
+            elif op == "neg":
+                e = "-%s" % A
+            elif op == "abs":
+                e = "rmt_abs(%s)" % A
+            elif op == "powi":
+                n = abs(b)
+                terms, sq, cur = [], n, A
+                # binary powering with named squares
+                k = 0
+                sqname = A
+                while sq:
+                    if sq & 1:
+                        terms.append(sqname)
+                    sq >>= 1
+                    if sq:
+                        k += 1
+                        nm = "%s_s%d" % (v, k)
+                        pre.append("const real %s = %s * %s;" % (nm, sqname, sqname))
+                        sqname = nm
+                prod = " * ".join(terms)
+                if b < 0:
+                    pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (A, FLAG_DIV0))
+                    e = "real(1) / (%s)" % prod
+                else:
+                    e = prod
+            elif op == "pow":
+                pre.append("flag |= rmt_pow_flags(%s, %s);" % (A, B))
+                e = "rmt_pow(%s, %s)" % (A, B)
+            elif op in ("log", "log10", "log2", "log1p"):
+                bad = "<= real(0)" if op != "log1p" else "<= real(-1)"
+                pre.append("flag |= (%s %s) ? %du : 0u;" % (A, bad, FLAG_DOMAIN))
+                e = "rmt_%s(%s)" % (op, A)
+            elif op == "sqrt":
+                pre.append("flag |= (%s < real(0)) ? %du : 0u;" % (A, FLAG_DOMAIN))
+                e = "rmt_sqrt(%s)" % A
+            elif op in ("exp", "exp10", "exp2", "expm1", "sinh", "cosh"):
+                lim = {"exp": _EXP_MAX, "expm1": _EXP_MAX, "sinh": 710.4758600739439,
+                       "cosh": 710.4758600739439, "exp10": 308.2547155599167, "exp2": 1024.0}[op]
+                cond = ("%s > real(%r)" % (A, lim)) if op not in ("sinh", "cosh") else (
+                    "rmt_abs(%s) > real(%r)" % (A, lim))
+                pre.append("flag |= (%s) ? %du : 0u;" % (cond, FLAG_OVERFLOW))
+                e = "rmt_%s(%s)" % (op, A)
+            elif op in ("sin", "cos", "tan", "tanh", "atan"):
+                e = "rmt_%s(%s)" % (op, A)
+            elif op in ("min", "max"):
+                e = "rmt_%s(%s, %s)" % (op, A, B)
+            else:
+                raise LoweringError("no device emission for op %r" % op)
+            for p in pre:
+                if p.startswith("flag |=") :
+                    if p in seen_checks:
+                        continue
+                    seen_checks.add(p)
+                lines.append("    " + p)
+            lines.append("    const real %s = %s;" % (v, e))
+            name[i] = v
+        body = "\n".join(lines)
+        outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
+        return (
+            "__device__ __forceinline__ void %s(const real T, const real P, const real* __restrict__ x,\n"
+            "        const real* __restrict__ C, real* __restrict__ r, unsigned& flag) {\n%s\n%s\n}\n"
+            % (fname, body, outs))
+
+
+def trace(VARS, RATES, nspecies, R_CONST=8.314472, fixed=None):
+    """Symbolic run of reactionRateExe (rmtReaction.py:27-58).  ``fixed`` optionally binds inputs
+    (e.g. {"T": 523.0}) to literals so that everything depending only on them is folded."""
+    g = Graph()
+    fixed = fixed or {}
+
+    def leaf(nm):
+        return g.const(fixed[nm]) if nm in fixed else g.inp(nm)
+
+    loopDict = {
+        "R_CONST": R_CONST,
+        "T": leaf("T"),
+        "P": leaf("P"),
+        "MoFri": SymVector([g.inp("x%d" % i) for i in range(nspecies)]),
+        "SpCoi": SymVector([g.inp("C%d" % i) for i in range(nspecies)]),
+    }
+    merged = {**loopDict, **VARS}
+    memo = {}
+    exe = {}
+    for k, v in merged.items():
+        if isinstance(v, types.FunctionType):
+            try:
+                exe[k] = rebind(v, memo)(exe)
+            except LoweringError:
+                raise
+            except Exception as e:
+                raise LoweringError("cannot trace VARS[%r]: %s: %s" % (k, type(e).__name__, e)) from e
+        else:
+            exe[k] = v
+    outs = []
+    for k, fn in RATES.items():
+        try:
+            val = rebind(fn, memo)(exe)
+        except LoweringError:
+            raise
+        except Exception as e:
+            raise LoweringError("cannot trace RATES[%r]: %s: %s" % (k, type(e).__name__, e)) from e
+        if not isinstance(val, Sym):
+            if not _num(val):
+                raise LoweringError("RATES[%r] returned %r" % (k, type(val)))
+            val = g.const(float(val))
+        outs.append(val.i)
+    return Lowered(g, outs, nspecies)

@@ -1,0 +1,259 @@
+"""Device-side driver of model N2: the replacement for the time loop of
+PackedBedHomoReactorClass.runN2 (PyREMOT/docs/pbHomoReactor.py:3556-3704).
+
+The reference calls scipy's solve_ivp once per output interval with a Python RHS
+(:3589-3610); here each interval is ONE launch of a device-resident explicit stepper
+(fixed-step RK4 or adaptive Dormand-Prince RK45) over all mesh nodes of all ensemble members.
+torch is used only as the owner of device memory and streams.
+"""
+import ctypes as C
+from timeit import default_timer as timer
+
+import numpy as np
+
+from . import hipbind, plan
+from .lowering import FLAG_DIV0, FLAG_DOMAIN, FLAG_NONFINITE, FLAG_OVERFLOW, FLAG_STEP
+from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
+
+DEVICE_IVPS = ("hip-rk4", "hip-rk45")
+
+
+def choose_geometry(N, V, fp32=False):
+    """(block, nodes_per_thread) of the generated kernels for a reactor of N nodes.
+    Register-resident steppers need N <= block*npt; beyond that the memory-resident ones run with
+    256-thread workgroups.  The table is what measured fastest on MI355X."""
+    for block in (64, 128, 256, 512):
+        if N <= block:
+            return block, 1
+    if N <= 1024:
+        return (512, 2) if V <= 8 else (1024, 1)
+    return 256, 1
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise hipbind.RmtN2Error("no HIP device visible: the N2 integrator has no CPU fallback")
+    return torch
+
+
+class N2Device:
+    """One compiled mechanism + E packed member rows on one GPU."""
+
+    def __init__(self, mech, members, N, fp32=False, block=None, npt=None, device=None,
+                 extra_opts=""):
+        torch = _torch()
+        self.torch = torch
+        self.mech, self.N, self.fp32 = mech, int(N), bool(fp32)
+        members = np.ascontiguousarray(members, dtype=np.float64)
+        if members.ndim == 1:
+            members = members.reshape(1, -1)
+        assert members.shape[1] == plan.MEMBER_FIXED + mech.S
+        self.E = members.shape[0]
+        self.members = members
+        b, n = choose_geometry(self.N, mech.V, fp32)
+        self.block, self.npt = int(block or b), int(npt or n)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        tpl = hipbind.kernel_template()
+        src = mech.source(tpl, self.fp32, self.block, self.npt)
+        key = mech.digest(tpl, self.fp32, self.block, self.npt)
+        arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
+        code = hipbind.compile_cached(src, key, arch, extra_opts)
+        self._code = C.create_string_buffer(code, len(code))
+        p = hipbind.Plan()
+        p.abi_version = hipbind.ABI_VERSION
+        p.n_species, p.n_reactions, p.n_vars = mech.S, mech.R, mech.V
+        p.n_nodes, p.n_members, p.fp32 = self.N, self.E, int(self.fp32)
+        p.block, p.nodes_per_thread = self.block, self.npt
+        p.code_object = C.cast(self._code, C.c_void_p)
+        p.code_size = len(code)
+        p.members = members.ctypes.data_as(C.POINTER(C.c_double))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            hipbind.check(hipbind.lib().rmt_n2_create(C.byref(p), C.byref(h)))
+        self.h = h
+        self.dtype = torch.float32 if self.fp32 else torch.float64
+        self._stats = torch.zeros((self.E, 4), dtype=torch.float64, device=self.device)
+        self.use_current_stream()
+
+    # -- plumbing
+    def use_current_stream(self):
+        s = self.torch.cuda.current_stream(self.device).cuda_stream
+        hipbind.check(hipbind.lib().rmt_n2_set_stream(self.h, C.c_void_p(s)))
+
+    def set_mode(self, mode):
+        hipbind.check(hipbind.lib().rmt_n2_set_mode(self.h, {"auto": 0, "reg": 1, "mem": 2}[mode]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            hipbind.lib().rmt_n2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def to_device(self, y):
+        t = self.torch.as_tensor(np.ascontiguousarray(y), dtype=self.dtype)
+        return t.reshape(self.E, self.mech.V*self.N).contiguous().to(self.device)
+
+    def _chk_state(self, y):
+        assert y.is_cuda and y.dtype == self.dtype and y.is_contiguous()
+        assert y.numel() == self.E*self.mech.V*self.N, "state must be [E][V][N]"
+
+    # -- hot path entry points
+    def rhs(self, y, t=0.0):
+        self._chk_state(y)
+        out = self.torch.empty_like(y)
+        hipbind.check(hipbind.lib().rmt_n2_rhs(self.h, float(t), C.c_void_p(y.data_ptr()),
+                                               C.c_void_p(out.data_ptr())))
+        return out
+
+    def rk4(self, y, dt, nsteps, t0=0.0):
+        """In place: nsteps RK4 steps of size dt."""
+        self._chk_state(y)
+        hipbind.check(hipbind.lib().rmt_n2_rk4(self.h, C.c_void_p(y.data_ptr()), float(t0), float(dt),
+                                               int(nsteps)))
+
+    def rk45(self, y, t0, t1, rtol, atol, h0, max_steps):
+        self._chk_state(y)
+        hipbind.check(hipbind.lib().rmt_n2_rk45(self.h, C.c_void_p(y.data_ptr()), float(t0), float(t1),
+                                                float(rtol), float(atol), float(h0), int(max_steps),
+                                                C.c_void_p(self._stats.data_ptr())))
+
+    def rk45_stats(self):
+        raw = self._stats.cpu().numpy()
+        return {"t_end": raw[:, 0].copy(), "h_last": raw[:, 1].copy(),
+                "accepted": raw[:, 2].copy().view(np.int64), "rejected": raw[:, 3].copy().view(np.int64)}
+
+    def status(self):
+        flags = np.zeros(self.E, dtype=np.uint32)
+        hipbind.check(hipbind.lib().rmt_n2_status(self.h, flags.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return flags
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        hipbind.check(hipbind.lib().rmt_n2_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def raise_on_flags(self):
+        """Turn device status words into the exception the reference's Python path raises inside
+        the user lambdas (SURVEY.md section 5 'Failure detection')."""
+        flags = self.status()
+        bad = np.nonzero(flags)[0]
+        if len(bad) == 0:
+            return
+        f = int(flags[bad[0]])
+        where = "reactor %d of %d (flags=0x%x)" % (bad[0], self.E, f)
+        if f & FLAG_DOMAIN:
+            raise ValueError("math domain error in " + where)
+        if f & FLAG_DIV0:
+            raise ZeroDivisionError("float division by zero in " + where)
+        if f & FLAG_OVERFLOW:
+            raise OverflowError("math range error in " + where)
+        if f & FLAG_STEP:
+            raise RuntimeError("adaptive step control failed (step underflow / max steps) in " + where)
+        if f & FLAG_NONFINITE:
+            raise FloatingPointError("state became NaN/Inf in " + where + " - step size too large?")
+        raise RuntimeError("device error in " + where)
+
+
+# --------------------------------------------------------------------------- result packing
+def pack_interval(Y, named, mech, zNo, t_end, modelId):
+    """One dataPack entry (pbHomoReactor.py:3630-3678; sortResult5, solResultAnalysis.py:252-301)."""
+    S = mech.S
+    Y = np.reshape(np.asarray(Y, dtype=np.float64), (mech.V, zNo))
+    conc_dl = Y[:-1] if not mech.iso else Y[:]
+    temp_dl = Y[-1] if not mech.iso else np.repeat(0, zNo).reshape(zNo)
+    conc = conc_dl*named["Cmax"]
+    T_dl_row = Y[-1, :].reshape((1, zNo)) if not mech.iso else np.repeat(0, zNo).reshape((1, zNo))
+    Treal = T_dl_row*named["Tf"] + named["Tf"]
+    mofr = conc/np.sum(conc, axis=0)
+    labelList = list(mech.compList) + ["Temperature"]
+    return {
+        "modelId": modelId, "processType": mech.processType, "successStatus": True,
+        "dataShape": np.array(t_end).shape, "labelList": labelList, "indexList": [S, S + 1, S],
+        "dataTime": t_end, "dataXs": np.linspace(0, 1, zNo),
+        "dataYCons1": conc_dl, "dataYCons2": conc, "dataYTemp1": temp_dl, "dataYTemp2": Treal,
+        "dataYs": np.concatenate((mofr, Treal), axis=0),
+    }
+
+
+def _progress(i, total, quiet):
+    if quiet:
+        return
+    pct = ("{0:.1f}").format(100*(i/float(total)))
+    filled = int(50*i//total)
+    print('\rProgress: |%s| %s%% Complete' % ('█'*filled + '-'*(50 - filled), pct),
+          end="\r" if i < total else "\n")
+
+
+def run_n2(modelInput, members_inputs=None):
+    """runN2 on the device.  ``members_inputs``: optional list of modelInput dicts (one per
+    ensemble member, same mechanism); default = the single reactor described by modelInput."""
+    start = timer()
+    cfg = modelInput['solver-config']
+    ivp = cfg['ivp']
+    displayResult = cfg['display-result'] == "True"        # KeyError like the reference (:3337)
+    if ivp in ("default", "RK45"):
+        ivp = "hip-rk45"
+    if ivp not in DEVICE_IVPS:
+        raise ValueError("`ivp` must be one of %s (or 'default'); the device build has no "
+                         "implicit/CPU integrators (got %r)" % (DEVICE_IVPS, ivp))
+    zNo = int(cfg.get('zNo', solverSetting['N2']['zNo']))
+    tNo = int(cfg.get('tNo', solverSetting['N2']['tNo']))
+    fp32 = cfg.get('dtype', 'fp64') in ('fp32', 'float32')
+    quiet = bool(cfg.get('quiet', False))
+    opT = modelInput['operating-conditions']['period']
+    modelId = modelInput['model']
+
+    mech = plan.Mechanism(modelInput)
+    inputs = list(members_inputs) if members_inputs else [modelInput]
+    named_rows = [plan.member_constants(mi, mech, zNo) for mi in inputs]
+    rows = np.array([r for _, r in named_rows])
+    dev = N2Device(mech, rows, zNo, fp32=fp32, block=cfg.get('block'), npt=cfg.get('nodes-per-thread'))
+    try:
+        IV = np.array([plan.initial_state(nm, mech, zNo) for nm, _ in named_rows])
+        y = dev.to_device(IV)
+        opTSpan = np.linspace(0, opT, tNo + 1)
+        packs = [[] for _ in inputs]
+        stats = {"steps": 0, "rhs_evals": 0, "node_steps": 0, "accepted": None, "rejected": None}
+        _progress(0, tNo + 1, quiet)
+        for i in range(tNo):
+            t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
+            _progress(i + 1, tNo + 1, quiet)
+            if ivp == "hip-rk4":
+                dt_req = float(cfg.get('dt', DEVICE_DEFAULTS['rk4-dt']))
+                n = max(1, int(round((t1 - t0)/dt_req)))
+                dev.rk4(y, (t1 - t0)/n, n, t0)
+                stats["steps"] += n
+                stats["rhs_evals"] += 4*n
+            else:
+                dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
+                         float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])),
+                         float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0'])),
+                         int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
+            dev.raise_on_flags()
+            if ivp == "hip-rk45":
+                st = dev.rk45_stats()
+                stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
+                stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
+            Yh = y.cpu().numpy().astype(np.float64)
+            for e, (nm, _) in enumerate(named_rows):
+                packs[e].append(pack_interval(Yh[e], nm, mech, zNo, t1, modelId))
+        if stats["accepted"] is not None:
+            stats["steps"] = int(np.sum(stats["accepted"]))
+            stats["rhs_evals"] = int(np.sum(6*(stats["accepted"] + stats["rejected"])) + len(inputs)*tNo)
+        stats["node_steps"] = stats["steps"]*zNo*(len(inputs) if ivp == "hip-rk4" else 1)
+    finally:
+        dev.close()
+    elapsed = np.round(timer() - start, ROUND_FUN_ACCURACY)
+    resPack = {"computation-time": elapsed, "dataPack": packs[0], "device-stats": stats}
+    if members_inputs:
+        resPack["ensemble"] = [{"dataPack": p} for p in packs]
+    if displayResult:
+        from .plotting import plot_results_dynamic
+        plot_results_dynamic(resPack, tNo)
+    return resPack

@@ -1,0 +1,241 @@
+"""Host front-end of the N2 path: modelInput -> mechanism tables + packed per-reactor constants
++ generated kernel source.
+
+Mirrors the *setup* half of PackedBedHomoReactorClass.runN2 (PyREMOT/docs/pbHomoReactor.py:3334-3580)
+and of rmtCoreClass.initReaction / initComponentData (PyREMOT/docs/rmtCore.py:129-183), but instead
+of building nested dicts that the RHS re-reads on every call (:3741-3825) it produces
+
+  * ``Mechanism``  - everything that is identical for all members of an ensemble and becomes
+                     compile-time constants of the generated kernel (species, stoichiometry, MW,
+                     Cp polynomials, heats of reaction, the lowered rate lambdas);
+  * member rows    - 16+S doubles per reactor (layout: csrc/n2_kernels.inc ``M_*``) holding the
+                     operating-point dependent scalars, pre-combined so the kernel does no
+                     redundant work (e.g. the Ergun march coefficient of SURVEY.md section 5).
+"""
+import hashlib
+import math
+import re
+
+import numpy as np
+
+from . import compdb
+from .lowering import trace
+from .settings import MODEL_SETTING, PROCESS_SETTING
+
+R_CONST = 8.314472          # PyREMOT/core/constants.py:8
+PI_CONST = math.pi          # :14
+Tref = 273.15 + 25.00       # :23
+
+MEMBER_FIXED = 16
+# index of each scalar in a member row (must match csrc/n2_kernels.inc)
+MEMBER_FIELDS = {
+    "CMAX": 0, "TF": 1, "P0": 2, "THETA_IN": 3, "ALPHA_K": 4, "BETA": 5, "RHO_K": 6,
+    "INV_CP0": 7, "F1": 8, "FT": 9, "INV_DZ": 10, "INV_MACOTE": 11, "INV_HECOTE": 12,
+    "UA": 13, "TM": 14, "CIN": 16,
+}
+
+_SPECIES_RE = re.compile(r"([0-9.]*)([a-zA-Z0-9.]+)")
+
+
+def parse_reaction(expr):
+    """'CO2 + 3H2 <=> CH3OH + H2O' -> ([(sym, -coeff)...], [(sym, +coeff)...]).
+    Grammar of buildReactionCoefficient (PyREMOT/docs/rmtUtility.py:171-220): strip '<', '>' and
+    blanks, split on '=', then an optional numeric prefix and a symbol per term."""
+    sides = expr.replace("<", "").replace(">", "").replace(" ", "").split("=")
+    if len(sides) < 2:
+        raise ValueError("reaction %r has no '=' separator" % (expr,))
+    reac = [(s, -1.0*float(c) if c else -1.0) for c, s in _SPECIES_RE.findall(sides[0])]
+    prod = [(s, float(c) if c else 1.0) for c, s in _SPECIES_RE.findall(sides[1])]
+    return reac, prod
+
+
+def reaction_tables(reactionDict):
+    """reactionListSorted / reactionStochCoeff in the reference's shapes (rmtUtility.py:171-249)."""
+    srt, vec = [], []
+    for expr in reactionDict.values():
+        reac, prod = parse_reaction(expr)
+        srt.append({"reactants": [{"symbol": s, "coeff": c} for s, c in reac],
+                    "products": [{"symbol": s, "coeff": c} for s, c in prod]})
+        vec.append([[s, float(c)] for s, c in reac + prod])
+    return srt, vec
+
+
+def build_component_list(componentDataDict):
+    """buildComponentList (rmtUtility.py:312-340): shell + tube + medium, de-duplicated."""
+    out = []
+    for key in ("shell", "tube", "medium"):
+        part = componentDataDict.get(key)
+        if part:
+            out.extend(part)
+    return list(dict.fromkeys(out))
+
+
+def wilke(visc, x, MW):
+    """Wilke mixing rule, calMixturePropertyM1 (PyREMOT/docs/gasTransPor.py:229-274)."""
+    n = len(visc)
+    phi = np.ones((n, n))
+    for i in range(n):
+        for j in range(i + 1, n):
+            A = 1 + math.sqrt(visc[i]/visc[j])*((MW[j]/MW[i])**(1/4))
+            phi[i, j] = (A**2)/math.sqrt(8*(1 + (MW[i]/MW[j])))
+            phi[j, i] = (visc[j]/visc[i])*(MW[i]/MW[j])*phi[i, j]
+    tot = 0.0
+    for i in range(n):
+        tot += visc[i]*x[i]/np.sum(x*phi[i, :])
+    return tot
+
+
+class Mechanism:
+    """Ensemble-invariant part of a model: becomes literals in the generated kernel."""
+
+    def __init__(self, modelInput):
+        mi = modelInput
+        self.compList = list(mi['feed']['components']['shell'])
+        for s in build_component_list(mi['feed']['components']):
+            if s not in compdb.componentSymbolList:
+                raise Exception("Component database is not up to date!")       # rmt.py:55-57
+        self.S = len(self.compList)
+        self.processType = mi['operating-conditions']['process-type']
+        self.iso = self.processType == PROCESS_SETTING['ISO-THER']
+        self.V = self.S if self.iso else self.S + 1
+        self.reactionDict = dict(mi['reactions'])
+        self.reactionListSorted, self.reactionStochCoeff = reaction_tables(self.reactionDict)
+        self.R = len(self.reactionStochCoeff)
+        self.MW = [compdb.COMPONENTS[s].MW for s in self.compList]
+        # dense stoichiometric matrix: componentFormationRate (rmtReaction.py:64-97) sums every
+        # occurrence of a species in a reaction; calEnthalpyChangeOfReaction (rmtThermo.py:258-312)
+        # does the same with the Cp's, so one matrix serves both.
+        self.nu = np.zeros((self.R, self.S))
+        for k, rx in enumerate(self.reactionStochCoeff):
+            for sym, c in rx:
+                if sym in self.compList:
+                    self.nu[k, self.compList.index(sym)] += c
+        self.cp_coeff = np.array([compdb.COMPONENTS[s].cp for s in self.compList], dtype=float)
+        self.cp_ref = np.array([compdb.cp_value(s, Tref) for s in self.compList])
+        self.StHeRe25 = np.array([self._standard_heat(expr) for expr in self.reactionDict.values()])
+        rr = mi['reaction-rates']
+        self.lowered = trace(rr['VARS'], rr['RATES'], self.S, R_CONST)
+        if len(self.lowered.outputs) != self.R:
+            raise ValueError("%d rate expressions for %d reactions" % (len(self.lowered.outputs), self.R))
+
+    @staticmethod
+    def _standard_heat(expr):
+        """calStandardEnthalpyOfReaction (rmtThermo.py:129-198) [kJ/kmol == J/mol]."""
+        reac, prod = parse_reaction(expr)
+        hr = np.sum(np.array([compdb.COMPONENTS[s].dHf25*(-c) for s, c in reac
+                              if s in compdb.COMPONENTS]))
+        hp = np.sum(np.array([compdb.COMPONENTS[s].dHf25*c for s, c in prod
+                              if s in compdb.COMPONENTS]))
+        return (hp - hr)*1000.00
+
+    # ------------------------------------------------------------------ kernel source
+    def prelude(self, fp32=False, block=1024, npt=1):
+        def arr(vals):
+            return "{" + ", ".join("real(%r)" % float(v) for v in vals) + "}"
+        S, R = self.S, self.R
+        lines = [
+            "// generated by rmt_app_amd.plan.Mechanism.prelude - do not edit",
+            "#define RMT_S %d" % S,
+            "#define RMT_R %d" % R,
+            "#define RMT_ISO %d" % (1 if self.iso else 0),
+            "#define RMT_FP32 %d" % (1 if fp32 else 0),
+            "#define RMT_BLOCK %d" % block,
+            "#define RMT_NPT %d" % npt,
+            "typedef %s real;" % ("float" if fp32 else "double"),
+            "__device__ static const real RMT_MW[RMT_S] = %s;" % arr(self.MW),
+            "__device__ static const real RMT_CP[RMT_S][4] = {%s};" % ", ".join(
+                arr(row) for row in self.cp_coeff),
+            "__device__ static const real RMT_CPREF[RMT_S] = %s;" % arr(self.cp_ref),
+            "__device__ static const real RMT_NU[RMT_R][RMT_S] = {%s};" % ", ".join(
+                arr(row) for row in self.nu),
+            "__device__ static const real RMT_DH25[RMT_R] = %s;" % arr(self.StHeRe25),
+        ]
+        return "\n".join(lines) + "\n"
+
+    def source(self, template, fp32=False, block=1024, npt=1):
+        """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
+        if "RMT_KINETICS_SOURCE" not in template:
+            raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
+        body = template.replace("RMT_KINETICS_SOURCE", self.lowered.emit("rmt_kinetics"), 1)
+        return self.prelude(fp32, block, npt) + body
+
+    def digest(self, template, fp32, block, npt):
+        h = hashlib.sha256()
+        h.update(self.source(template, fp32, block, npt).encode())
+        return h.hexdigest()[:24]
+
+
+def member_constants(modelInput, mech, zNo):
+    """One reactor's scalars: the arithmetic of runN2's setup block (pbHomoReactor.py:3341-3466),
+    returned both as a dict of named reference quantities (for parity tests and result packing)
+    and as the packed row the kernels read."""
+    mi = modelInput
+    P = mi['operating-conditions']['pressure']
+    T = mi['operating-conditions']['temperature']
+    ReSpec = mi['reactor']
+    ReInDi, ReLe = ReSpec['ReInDi'], ReSpec['ReLe']
+    PaDi, BeVoFr = ReSpec['PaDi'], ReSpec['BeVoFr']
+    CrSeAr = PI_CONST*(ReInDi**2)/4                                   # :3377
+    VoFlRa0 = mi['feed']['volumetric-flowrate']
+    SpCoi0 = np.array(mi['feed']['concentration'], dtype=float)
+    if SpCoi0.shape != (mech.S,):
+        raise ValueError("feed.concentration must have one entry per shell component")
+    SpCo0 = np.sum(SpCoi0)
+    InGaVe0 = VoFlRa0/(CrSeAr*BeVoFr)                                 # :3391
+    SuGaVe0 = InGaVe0*BeVoFr                                          # :3393
+    MoFri0 = SpCoi0/np.sum(SpCoi0)                                    # :3396
+    MoWei = np.array(mech.MW, dtype=float)
+    ExHe = mi['external-heat']
+    Tm, U = ExHe['MeTe'], ExHe['OvHeTrCo']
+    a = 4/ReInDi                                                      # :3411 (EfHeTrAr ignored)
+    GaVii0 = np.array([compdb.viscosity(s, T) for s in mech.compList])
+    GaMiVi = wilke(GaVii0, MoFri0, MoWei)                             # :3415-3416
+    GaCpMeanList0 = np.array([(compdb.cp_value(s, Tref) + compdb.cp_value(s, T))*0.50
+                              for s in mech.compList])                # :3420
+    GaCpMeanMix0 = np.dot(MoFri0, GaCpMeanList0)                      # :3422
+    MiMoWe0 = np.dot(MoFri0, MoWei)*1e-3                              # :3426
+    GaDe0 = MiMoWe0*SpCo0                                             # :3429
+    dz = 1/(zNo - 1)                                                  # :3439 (DoLe = 1)
+    Tf, Pf, vf, zf, Cpf = T, P, SuGaVe0, ReLe, GaCpMeanMix0
+    Cmax = np.max(SpCoi0)
+    if MODEL_SETTING['GaMaCoTe0'] != "MAX":
+        raise NotImplementedError("only MODEL_SETTING['GaMaCoTe0'] == 'MAX' is supported")
+    GaMaCoTe0 = (vf/zf)*np.repeat(Cmax, mech.S)                       # :3462-3464
+    GaHeCoTe0 = (GaDe0*vf*Tf*(Cpf/MiMoWe0)/zf)                        # :3466
+    ergA = 150*GaMiVi*SuGaVe0/(PaDi**2)                               # :3970-3973 with v == vf
+    ergB = ((1 - BeVoFr)**2)/(BeVoFr**3)
+    ergD = (1 - BeVoFr)/(BeVoFr**3)
+    named = {
+        "CrSeAr": CrSeAr, "SpCoi0": SpCoi0, "SpCo0": SpCo0, "SuGaVe0": SuGaVe0, "GaMiVi": GaMiVi,
+        "GaDe0": GaDe0, "GaCpMeanMix0": GaCpMeanMix0, "MiMoWe0": MiMoWe0, "dz": dz,
+        "Tf": Tf, "Pf": Pf, "vf": vf, "zf": zf, "Cpif": GaCpMeanList0, "Cpf": Cpf,
+        "GaMaCoTe0": GaMaCoTe0, "GaHeCoTe0": GaHeCoTe0, "EfHeTrAr": a, "Cmax": Cmax,
+        "P0": P, "T0": T, "VoFlRa0": VoFlRa0, "U": U, "Tm": Tm,
+    }
+    row = np.zeros(MEMBER_FIXED + mech.S)
+    F = MEMBER_FIELDS
+    row[F["CMAX"]] = Cmax
+    row[F["TF"]] = Tf
+    row[F["P0"]] = P
+    row[F["THETA_IN"]] = (T - Tf)/Tf                                   # :4108
+    row[F["ALPHA_K"]] = dz*1.75*(SuGaVe0**2)*ergD/(PaDi*R_CONST)
+    row[F["BETA"]] = -dz*ergA*ergB
+    row[F["RHO_K"]] = 1.0/(R_CONST*GaDe0)
+    row[F["INV_CP0"]] = 1.0/GaCpMeanMix0
+    row[F["F1"]] = 1/(BeVoFr*(zf/vf))                                  # const_F1, :4075
+    row[F["FT"]] = vf/zf
+    row[F["INV_DZ"]] = float(zNo - 1)
+    row[F["INV_MACOTE"]] = 1.0/GaMaCoTe0[0]
+    row[F["INV_HECOTE"]] = 1.0/GaHeCoTe0
+    row[F["UA"]] = U*a
+    row[F["TM"]] = Tm
+    row[F["CIN"]:F["CIN"] + mech.S] = SpCoi0/Cmax                      # :4090
+    return named, row
+
+
+def initial_state(named, mech, zNo):
+    """IV2D flattened (pbHomoReactor.py:3483-3497)."""
+    IV = np.zeros((mech.V, zNo))
+    for i in range(mech.S):
+        IV[i, :] = named["SpCoi0"][i]/np.max(named["SpCoi0"])
+    return IV.flatten()

@@ -1,0 +1,32 @@
+"""Global solver / model switches, mirroring the reference's module-level dicts.
+
+``solverSetting``  <- PyREMOT/solvers/solSetting.py:30-106 (only the entries the N2 path reads:
+                      N2.zNo/tNo/timesNo at pbHomoReactor.py:3435,3557,3561 and
+                      T1.ode-solver.PreCorr3.n at :3572).  Like the reference's dict it is a plain
+                      mutable object read at run time, so ``solverSetting['N2']['zNo'] = 1024``
+                      before ``rmtExe`` changes the mesh exactly as it does there.
+``MODEL_SETTING``  <- PyREMOT/docs/modelSetting.py:10-18;  ``PROCESS_SETTING`` <- :21-23.
+
+The device build additionally reads optional per-run overrides from
+``modelInput['solver-config']`` (keys zNo, tNo, dt, rtol, atol, dtype, max-steps); absent keys
+mean "reference behaviour".
+"""
+solverSetting = {
+    "N1": {"zNo": 100},
+    "N2": {"zNo": 20, "rNo": 5, "tNo": 5, "timesNo": 5},
+    "T1": {"ode-solver": {"PreCorr3": {"n": 100}}},
+}
+
+MODEL_SETTING = {"GaMaCoTe0": "MAX"}
+PROCESS_SETTING = {"ISO-THER": "iso-thermal"}
+
+# defaults of the device integrators (not in the reference: it delegates to scipy's defaults)
+DEVICE_DEFAULTS = {
+    "rk45-rtol": 1e-6,
+    "rk45-atol": 1e-9,
+    "rk45-h0": 1e-6,
+    "rk45-max-steps": 50_000_000,
+    "rk4-dt": 1e-5,
+}
+
+ROUND_FUN_ACCURACY = 3   # PyREMOT/core/config.py:8-24 ("computation-time" rounding)

@@ -1,0 +1,186 @@
+"""GPU parity tests: the HIP path (through the C-ABI library) against the reference-generated
+golden vectors and against the CPU oracle on the same seeded inputs.  fp64 tolerances:
+RHS <= 1e-12 row-relative; fixed-step RK4 trajectories <= 1e-9; outlet mole fractions and
+temperature <= 1e-6 relative versus the tight-tolerance SciPy run of the reference RHS."""
+import os
+
+import numpy as np
+import pytest
+
+import inputs as INP
+from oracle import n2_oracle as O
+from rmt_app_amd import plan, rmtExe, solverSetting
+from rmt_app_amd.n2 import N2Device
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rowwise_err(a, b, V):
+    a = np.asarray(a, float).reshape(V, -1)
+    b = np.asarray(b, float).reshape(V, -1)
+    den = np.max(np.abs(b), axis=1)
+    den[den == 0] = 1.0
+    return np.max(np.max(np.abs(a - b), axis=1)/den)
+
+
+def make_device(name, zNo, E=1, **kw):
+    mi = INP.ALL_N2_INPUTS[name]() if isinstance(name, str) else name
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, zNo)
+    dev = N2Device(mech, np.tile(row, (E, 1)), zNo, **kw)
+    return mi, mech, nm, dev
+
+
+RHS_CASES = [("dme_nb", 20), ("dme_nb", 100), ("dme_nb", 1024), ("dme_script", 20),
+             ("dme_script", 100), ("ch4", 20), ("ch4", 100), ("syn12", 20), ("syn12", 100)]
+
+
+@pytest.mark.parametrize("name,zNo", RHS_CASES)
+def test_rhs_vs_reference_golden(name, zNo):
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["%s_%d_y" % (name, zNo)], g["%s_%d_f" % (name, zNo)]
+    _, mech, _, dev = make_device(name, zNo, E=len(Y))
+    out = dev.rhs(dev.to_device(Y)).cpu().numpy()
+    assert not dev.status().any()
+    for k in range(len(Y)):
+        assert rowwise_err(out[k], F[k], mech.V) < 1e-12, k
+    dev.close()
+
+
+@pytest.mark.parametrize("block", [64, 128, 256, 1024])
+def test_rhs_block_sizes_and_ragged_tail(block):
+    """N not a multiple of the workgroup: several node blocks with carry + a ragged tail."""
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["dme_nb_100_y"], g["dme_nb_100_f"]
+    _, mech, _, dev = make_device("dme_nb", 100, E=len(Y), block=block, npt=1)
+    out = dev.rhs(dev.to_device(Y)).cpu().numpy()
+    for k in range(len(Y)):
+        assert rowwise_err(out[k], F[k], mech.V) < 1e-12
+    dev.close()
+
+
+def test_rhs_isothermal():
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["dme_nb_iso_20_y"], g["dme_nb_iso_20_f"]
+    _, mech, _, dev = make_device(INP.dme_notebook_input(process_type="iso-thermal"), 20, E=len(Y))
+    out = dev.rhs(dev.to_device(Y)).cpu().numpy()
+    for k in range(len(Y)):
+        assert rowwise_err(out[k], F[k], 6) < 1e-12
+    dev.close()
+
+
+@pytest.mark.parametrize("name,zNo", [("dme_nb", 20), ("dme_script", 20), ("dme_nb", 100),
+                                      ("ch4", 20), ("syn12", 20)])
+@pytest.mark.parametrize("mode", ["reg", "mem"])
+def test_rk4_vs_reference_trajectory(name, zNo, mode):
+    g = np.load(os.path.join(G, "g3_rk4.npz"))
+    key = "%s_%d" % (name, zNo)
+    traj, h, n, stride = g[key + "_traj"], float(g[key + "_h"]), int(g[key + "_n"]), int(g[key + "_stride"])
+    _, mech, nm, dev = make_device(name, zNo)
+    dev.set_mode(mode)
+    y = dev.to_device(plan.initial_state(nm, mech, zNo))
+    done = 0
+    scale = np.maximum(np.max(np.abs(traj), axis=1), 1e-300)
+    for col in (1, traj.shape[1]//2, traj.shape[1] - 1):
+        steps = col*stride
+        dev.rk4(y, h, steps - done)
+        done = steps
+        got = y.cpu().numpy()[0]
+        assert np.max(np.abs(got - traj[:, col])/scale) < 1e-9, col
+    assert not dev.status().any()
+    dev.close()
+
+
+@pytest.mark.parametrize("block,npt", [(64, 1), (64, 2), (128, 1), (256, 4), (512, 2), (1024, 1)])
+def test_rk4_geometries_agree_with_oracle(block, npt):
+    """Every (workgroup, nodes-per-thread) shape of the register stepper, incl. ragged N."""
+    N = min(block*npt, 1000) - 3
+    mi, mech, nm, dev = make_device("dme_nb", N, block=block, npt=npt)
+    y = dev.to_device(plan.initial_state(nm, mech, N))
+    dev.rk4(y, 1e-5, 12)
+    pr = O.setup_n2(mi, N)
+    want = O.rk4(0.0, 12e-5, 12, pr["IV"], O.make_rhs_vec(pr), keep=False)
+    got = y.cpu().numpy()[0]
+    scale = np.max(np.abs(want.reshape(7, N)), axis=1, keepdims=True)
+    assert np.max(np.abs(got.reshape(7, N) - want.reshape(7, N))/scale) < 1e-11
+    dev.close()
+
+
+def test_full_size_1024_ensemble_properties():
+    """BASELINE config 2/4 sizes: N=1024, E members.  Identical members stay bit-identical,
+    the oracle agrees after a short run, and a T/P-perturbed member differs."""
+    N, E = 1024, 8
+    mi = INP.dme_notebook_input()
+    mech = plan.Mechanism(mi)
+    rows, named = [], []
+    for e in range(E):
+        m2 = INP.dme_notebook_input()
+        if e == E - 1:
+            m2["operating-conditions"]["temperature"] = 533
+        nm, row = plan.member_constants(m2, mech, N)
+        rows.append(row), named.append(nm)
+    dev = N2Device(mech, np.array(rows), N)
+    y = dev.to_device(np.array([plan.initial_state(nm, mech, N) for nm in named]))
+    dev.rk4(y, 1e-5, 40)
+    assert not dev.status().any()
+    got = y.cpu().numpy()
+    for e in range(1, E - 1):
+        np.testing.assert_array_equal(got[e], got[0])
+    assert np.max(np.abs(got[E - 1] - got[0])) > 1e-6
+    pr = O.setup_n2(mi, N)
+    want = O.rk4(0.0, 40e-5, 40, pr["IV"], O.make_rhs_vec(pr), keep=False)
+    scale = np.max(np.abs(want.reshape(7, N)), axis=1, keepdims=True)
+    assert np.max(np.abs(got[0].reshape(7, N) - want.reshape(7, N))/scale) < 1e-10
+    # memory-resident stepper gives the same answer at this size
+    dev.set_mode("mem")
+    y2 = dev.to_device(np.array([plan.initial_state(nm, mech, N) for nm in named]))
+    dev.rk4(y2, 1e-5, 40)
+    assert np.max(np.abs(y2.cpu().numpy()[0] - got[0])) < 1e-12
+    dev.close()
+
+
+def test_large_mesh_memory_stepper_4096():
+    N = 4096
+    mi, mech, nm, dev = make_device("dme_nb", N)
+    y = dev.to_device(plan.initial_state(nm, mech, N))
+    dev.rk4(y, 1e-5, 10)
+    pr = O.setup_n2(mi, N)
+    want = O.rk4(0.0, 10e-5, 10, pr["IV"], O.make_rhs_vec(pr), keep=False)
+    scale = np.max(np.abs(want.reshape(7, N)), axis=1, keepdims=True)
+    assert np.max(np.abs(y.cpu().numpy()[0].reshape(7, N) - want.reshape(7, N))/scale) < 1e-10
+    dev.close()
+
+
+def test_flags_become_python_exceptions():
+    mi, mech, nm, dev = make_device("dme_nb", 20)
+    y0 = plan.initial_state(nm, mech, 20).reshape(7, 20).copy()
+    y0[6, 3] = -1.5                       # T < 0 -> math.log(T) raises ValueError in the reference
+    dev.rhs(dev.to_device(y0.flatten()))
+    with pytest.raises(ValueError, match="math domain error"):
+        dev.raise_on_flags()
+    assert not dev.status().any()         # flags are cleared once read
+    y = dev.to_device(plan.initial_state(nm, mech, 20))
+    dev.rk4(y, 5e-3, 50)                  # far beyond the stability limit -> blows up
+    with pytest.raises((OverflowError, FloatingPointError, ValueError, ZeroDivisionError)):
+        dev.raise_on_flags()
+    dev.close()
+
+
+def test_rmtexe_rk4_end_to_end_vs_tight_scipy_reference():
+    """BASELINE metric 'max |dMoFri| vs SciPy ref': rmtExe(hip-rk4) against the reference run
+    with LSODA/BDF at rtol<=1e-9 (golden G4), all five output times, outlet node."""
+    g = np.load(os.path.join(G, "g4_tight_dme_script_bdf.npz"))
+    mi = INP.dme_script_input(ivp="hip-rk4")
+    mi["solver-config"].update({"dt": 5e-6, "quiet": True})
+    res = rmtExe(mi)
+    dp = res["resModel"]["dataPack"]
+    assert len(dp) == solverSetting["N2"]["tNo"] == 5
+    worst = 0.0
+    for k in range(5):
+        a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
+        worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
+        assert abs(dp[k]["dataTime"] - float(g["dataTime_%d" % k])) < 1e-12
+    assert worst < 1e-6, worst
+    full = np.max(np.abs(dp[4]["dataYs"] - g["dataYs_4"])/np.abs(g["dataYs_4"]))
+    assert full < 5e-6, full

@@ -1,0 +1,268 @@
+"""CPU-only tests of the product's host side: lowering, plan constants vs the reference goldens,
+C-ABI library exports, hipRTC cross-compilation of the generated kernels, and the host
+emulation of the generated source against the reference RHS goldens.  No GPU compute."""
+import ctypes
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import inputs as INP
+from oracle import n2_oracle as O
+from oracle.hostemu import HostEmu
+from rmt_app_amd import compdb, hipbind, lowering, plan
+from rmt_app_amd.n2 import choose_geometry, pack_interval
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b)/np.maximum(np.abs(b), 1e-300))
+
+
+def rowwise_err(a, b, V):
+    a = np.asarray(a, float).reshape(V, -1)
+    b = np.asarray(b, float).reshape(V, -1)
+    den = np.max(np.abs(b), axis=1)
+    den[den == 0] = 1.0
+    return np.max(np.max(np.abs(a - b), axis=1)/den)
+
+
+@pytest.fixture(scope="module")
+def template():
+    return hipbind.kernel_template()
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rmt_n2.h")).read()
+    declared = set(re.findall(r"\b(rmt_n2_[a-z0-9_]+)\s*\(", hdr))
+    assert {"rmt_n2_create", "rmt_n2_rhs", "rmt_n2_rk4", "rmt_n2_rk45", "rmt_n2_status",
+            "rmt_n2_destroy", "rmt_n2_last_error", "rmt_n2_compile"} <= declared
+    L = ctypes.CDLL(hipbind.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert hipbind.lib().rmt_n2_abi_version() == 1
+    tpl = hipbind.kernel_template()
+    assert tpl == open(os.path.join(ROOT, "rmt_app_amd", "csrc", "n2_kernels.inc")).read()
+
+
+def test_create_rejects_bad_plans_and_reports_errors():
+    L = hipbind.lib()
+    p = hipbind.Plan()
+    h = ctypes.c_void_p()
+    assert L.rmt_n2_create(ctypes.byref(p), ctypes.byref(h)) != 0
+    assert b"ABI version" in L.rmt_n2_last_error()
+    p.abi_version = 1
+    assert L.rmt_n2_create(ctypes.byref(p), ctypes.byref(h)) != 0
+    assert b"bad plan sizes" in L.rmt_n2_last_error()
+    with pytest.raises(hipbind.RmtN2Error):
+        hipbind.compile_source("this is not HIP")
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rmt_app_amd import rmtExe
+    with pytest.raises(hipbind.RmtN2Error):
+        rmtExe(INP.dme_notebook_input(ivp="hip-rk4"))
+
+
+@pytest.mark.parametrize("name", list(INP.ALL_N2_INPUTS))
+def test_generated_kernels_cross_compile_for_gfx950(name, template):
+    mech = plan.Mechanism(INP.ALL_N2_INPUTS[name]())
+    block, npt = choose_geometry(1024, mech.V)
+    blob = hipbind.compile_cached(mech.source(template, False, block, npt),
+                                  mech.digest(template, False, block, npt), "gfx950")
+    assert blob[:4] == b"\x7fELF" and len(blob) > 4096
+    for sym in (b"rmt_n2_rhs", b"rmt_n2_rk4_reg", b"rmt_n2_rk4_mem"):
+        assert sym in blob
+
+
+# ----------------------------------------------------------------------------- lowering
+@pytest.mark.parametrize("name", list(INP.ALL_N2_INPUTS))
+def test_trace_is_bit_identical_to_direct_lambda_evaluation(name):
+    mi = INP.ALL_N2_INPUTS[name]()
+    S = len(mi['feed']['components']['shell'])
+    rr = mi['reaction-rates']
+    low = lowering.trace(rr['VARS'], rr['RATES'], S)
+    rng = np.random.default_rng(3)
+    for _ in range(25):
+        T, P = rng.uniform(450, 1000), rng.uniform(1e5, 6e6)
+        x = rng.random(S) + 0.01
+        x /= x.sum()
+        C = x*P/(8.314472*T)
+        want = O.reaction_rate_exe((T, P, x, C), rr['VARS'], rr['RATES'])
+        assert low.evaluate(T, P, x, C) == [float(w) for w in want]
+
+
+def test_dme_dag_statistics_and_source_shape():
+    rr = INP.dme_notebook_input()['reaction-rates']
+    low = lowering.trace(rr['VARS'], rr['RATES'], 6)
+    st = low.stats()
+    assert st["exp"] == 8 and st["log"] == 1 and st["log10"] == 1 and st["sqrt"] == 1 and st["exp10"] == 1
+    src = low.emit()
+    assert "rmt_kinetics" in src and src.count("rmt_exp(") == 8 and "r[2] =" in src
+    assert not low.uses("C0") and low.uses("x0") and low.uses("T") and low.uses("P")
+
+
+def test_closures_and_direct_imports_are_rebound():
+    from math import exp as my_exp, log
+
+    def helper(k0, Ea, x):
+        return k0*my_exp(-Ea/(x['R_CONST']*x['T']))
+
+    VARS = {"A": 2.5, "k": lambda x: helper(3.0, 1.0e4, x), "lnT": lambda x: log(x['T'], 10)}
+    RATES = {"r1": lambda x: x['k']*x['SpCoi'][1]**1.5*np.sqrt(x['MoFri'][0]) + x['A']*x['lnT']}
+    low = lowering.trace(VARS, RATES, 2)
+    T, P, x, C = 600.0, 2e5, np.array([0.3, 0.7]), np.array([10.0, 30.0])
+    want = O.reaction_rate_exe((T, P, x, C), VARS, RATES)[0]
+    assert abs(low.evaluate(T, P, x, C)[0] - want) <= 1e-15*abs(want)
+    assert "rmt_pow(" in low.emit()
+
+
+def test_untraceable_constructs_raise_not_fallback():
+    with pytest.raises(lowering.LoweringError):
+        lowering.trace({}, {"r": lambda x: 1.0 if x['T'] > 500 else 2.0}, 2)
+    with pytest.raises(lowering.LoweringError):
+        lowering.trace({}, {"r": lambda x: math.gamma(x['T'])}, 2)
+    with pytest.raises(lowering.LoweringError):
+        lowering.trace({}, {"r": lambda x: x['MoFri'][x['T']]}, 2)
+
+
+def test_domain_checks_are_emitted():
+    low = lowering.trace({}, {"r": lambda x: math.log(x['P'] - 1e5)/x['MoFri'][0] + math.exp(x['T'])}, 1)
+    src = low.emit()
+    assert "<= real(0)) ? 1u" in src and "== real(0)) ? 2u" in src and "709.78" in src
+
+
+# ----------------------------------------------------------------------------- plan vs reference
+@pytest.mark.parametrize("name", list(INP.ALL_N2_INPUTS))
+def test_plan_constants_vs_reference_setup(name):
+    with open(os.path.join(G, "g1_setup.json")) as f:
+        g = json.load(f)[name]
+    mi = INP.ALL_N2_INPUTS[name]()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, 20)
+    c, bc, dap = g["const"], g["constBC1"], g["DimensionlessAnalysisParams"]
+    assert mech.MW == c["MoWei"] and mech.V == c["varNo"] and mech.R == c["reactionListNo"]
+    assert np.max(np.abs(mech.StHeRe25 - np.array(c["StHeRe25"]))) < 1e-9
+    assert mech.reactionListSorted == g["reactionListSorted"]
+    assert mech.reactionStochCoeff == g["reactionStochCoeff"]
+    for k, ref in (("CrSeAr", c["CrSeAr"]), ("GaMiVi", c["GaMiVi"]), ("dz", c["dz"]),
+                   ("SuGaVe0", bc["SuGaVe0"]), ("GaDe0", bc["GaDe0"]), ("GaCpMeanMix0", bc["GaCpMeanMix0"]),
+                   ("SpCo0", bc["SpCo0"]), ("vf", dap["vf"]), ("Cpf", dap["Cpf"]), ("Cpif", dap["Cpif"]),
+                   ("GaMaCoTe0", dap["GaMaCoTe0"]), ("GaHeCoTe0", dap["GaHeCoTe0"]),
+                   ("EfHeTrAr", g["ExHe"]["EfHeTrAr"])):
+        assert relerr(nm[k], ref) < 1e-14, k
+    np.testing.assert_array_equal(plan.initial_state(nm, mech, 20), g["IV"])
+    F = plan.MEMBER_FIELDS
+    assert row[F["INV_DZ"]] == 19 and row[F["TM"]] == g["ExHe"]["MeTe"]
+    assert relerr(row[F["F1"]], dap["vf"]/(mi["reactor"]["BeVoFr"]*dap["zf"])) < 1e-15
+    np.testing.assert_allclose(row[F["CIN"]:], np.array(g["IV"]).reshape(c["varNo"], 20)[:mech.S, 0], rtol=1e-16)
+
+
+def test_component_table_vs_reference_probes():
+    with open(os.path.join(G, "g7_helpers.json")) as f:
+        g = json.load(f)
+    assert list(compdb.componentSymbolList) == g["components"]
+    assert [compdb.COMPONENTS[s].MW for s in g["components"]] == g["MW"]
+    assert [compdb.COMPONENTS[s].dHf25 for s in g["components"]] == g["dHf25"]
+    mf, MW = np.array(g["molefrac"]), np.array(g["MW"])
+    for p in g["probes"]:
+        T = p["T"]
+        assert relerr([compdb.cp_value(s, T) for s in g["components"]], p["Cp"]) < 1e-15
+        vis = np.array([compdb.viscosity(s, T) for s in g["components"]])
+        assert relerr(vis, p["GaVii"]) < 1e-15
+        assert relerr(plan.wilke(vis, mf, MW), p["GaMiVi"]) < 1e-14
+
+
+def test_unknown_component_and_bad_inputs():
+    mi = INP.dme_notebook_input()
+    mi["feed"]["components"]["shell"] = ["H2", "Xe"]
+    with pytest.raises(Exception, match="Component database is not up to date!"):
+        plan.Mechanism(mi)
+    mi = INP.dme_notebook_input()
+    mi["feed"]["concentration"] = [1.0, 2.0]
+    with pytest.raises(ValueError):
+        plan.member_constants(mi, plan.Mechanism(INP.dme_notebook_input()), 20)
+    from rmt_app_amd import rmtExe
+    with pytest.raises(NotImplementedError):
+        rmtExe(dict(INP.dme_notebook_input(), model="M9"))
+
+
+# ----------------------------------------------------------------------------- generated source on CPU
+RHS_CASES = [("dme_nb", 20), ("dme_nb", 100), ("dme_nb", 1024), ("dme_script", 20),
+             ("dme_script", 100), ("ch4", 20), ("ch4", 100), ("syn12", 20), ("syn12", 100)]
+
+
+@pytest.mark.parametrize("name,zNo", RHS_CASES)
+def test_generated_node_physics_vs_reference_rhs(name, zNo, template):
+    """The same generated translation unit the GPU compiles, built for the host (test-only
+    emulation, oracle/hostemu_driver.cpp) reproduces the reference RHS goldens."""
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["%s_%d_y" % (name, zNo)], g["%s_%d_f" % (name, zNo)]
+    mi = INP.ALL_N2_INPUTS[name]()
+    mech = plan.Mechanism(mi)
+    _, row = plan.member_constants(mi, mech, zNo)
+    emu = HostEmu(mech.source(template), tag=name)
+    out, flags = emu.rhs(Y, np.tile(row, (len(Y), 1)), zNo)
+    assert not flags.any()
+    for k in range(len(Y)):
+        assert rowwise_err(out[k], F[k], mech.V) < 1e-12, k
+
+
+def test_generated_isothermal_variant(template):
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    mi = INP.dme_notebook_input(process_type="iso-thermal")
+    mech = plan.Mechanism(mi)
+    assert mech.V == 6 and "#define RMT_ISO 1" in mech.prelude()
+    _, row = plan.member_constants(mi, mech, 20)
+    emu = HostEmu(mech.source(template), tag="dme_iso")
+    Y, F = g["dme_nb_iso_20_y"], g["dme_nb_iso_20_f"]
+    out, _ = emu.rhs(Y, np.tile(row, (len(Y), 1)), 20)
+    for k in range(len(Y)):
+        assert rowwise_err(out[k], F[k], 6) < 1e-12
+
+
+def test_emulated_rk4_vs_reference_trajectory(template):
+    g = np.load(os.path.join(G, "g3_rk4.npz"))
+    mi = INP.dme_script_input()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, 20)
+    emu = HostEmu(mech.source(template), tag="dme_script")
+    traj = g["dme_script_20_traj"]
+    y, flags = emu.rk4(plan.initial_state(nm, mech, 20), row, 20, 1e-5, 200)
+    assert not flags.any()
+    scale = np.max(np.abs(traj[:, -1].reshape(7, 20)), axis=1, keepdims=True)
+    assert np.max(np.abs(y[0].reshape(7, 20) - traj[:, -1].reshape(7, 20))/scale) < 1e-11
+
+
+def test_device_flags_in_emulation(template):
+    mi = INP.dme_notebook_input()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, 20)
+    emu = HostEmu(mech.source(template), tag="dme_nb")
+    y = plan.initial_state(nm, mech, 20).reshape(7, 20).copy()
+    y[6, 5] = -1.5          # T = Tf*(1-1.5) < 0  -> log(T) domain error in Ln_KP1
+    _, flags = emu.rhs(y.flatten(), row, 20)
+    assert flags[0] & lowering.FLAG_DOMAIN
+
+
+def test_result_packing_matches_reference_schema():
+    g4 = np.load(os.path.join(G, "g4_tight_dme_script_bdf.npz"))
+    mi = INP.dme_script_input()
+    mech = plan.Mechanism(mi)
+    nm, _ = plan.member_constants(mi, mech, 20)
+    Y = np.concatenate([g4["dataYCons1_4"].flatten(), g4["dataYTemp1_4"].flatten()])
+    d = pack_interval(Y, nm, mech, 20, 0.5, "N2")
+    for key in ("dataYs", "dataYCons1", "dataYCons2", "dataYTemp1", "dataYTemp2", "dataXs"):
+        np.testing.assert_allclose(d[key], g4[key + "_4"], rtol=1e-15, atol=0)
+    assert d["labelList"] == INP.DME_COMPONENTS + ["Temperature"] and d["indexList"] == [6, 7, 6]
+    assert d["dataShape"] == () and d["successStatus"] is True and d["modelId"] == "N2"

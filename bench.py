@@ -2,7 +2,7 @@
 """bench.py - mesh-node-steps/s of the N2 hot path on MI355X (BASELINE.json metric).
 
 Workload (config.workload): BASELINE configs[1]'s reactor - the TEST2.ipynb DME case (6 species,
-3 reactions, fp64) on 1024 axial nodes, classic RK4 with dt = 1e-5 s - replicated as the
+3 reactions, fp64) on 1024 axial nodes, classic RK4 with dt = 2e-6 s (the stable step for this case) - replicated as the
 per-GPU shard of configs[3]'s ensemble: 256 independent reactors per GPU with the inlet-T /
 pressure sweep of SURVEY.md section 8(d).4 (2048 members at 8 GPUs).  One "step" = one RK4 time
 step (4 RHS evaluations) of every node of every member on this rank.  Ranks are independent
@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 N_NODES = 1024
 MEMBERS_PER_GPU = 256
-DT = 1e-5
+DT = 2e-6
 
 
 def sweep_member_inputs(first, count, total=2048):
@@ -154,7 +154,7 @@ def main():
             "value": value, "unit": "mesh-node-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3*tmax/args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "DME N2 (TEST2.ipynb reactor), %d nodes, RK4 dt=1e-5 s, %d "
+            "config": {"workload": "DME N2 (TEST2.ipynb reactor), %d nodes, RK4 dt=2e-6 s, %d "
                                    "reactors/GPU of the 64x32 inlet-T/P sweep" % (N_NODES, E),
                        "members_per_gpu": E, "nodes": N_NODES, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,

@@ -346,7 +346,7 @@ __device__ __forceinline__ void rmt_safe_state(const RmtMember& m, real* __restr
 __device__ __forceinline__ unsigned rmt_finite_flag(const real* __restrict__ v) {
     unsigned f = 0u;
 #pragma unroll
-    for (int i = 0; i < RMT_V; ++i) f |= (v[i] - v[i] == real(0)) ? 0u : RMT_FLAG_NONFINITE;
+    for (int i = 0; i < RMT_V; ++i) f |= __builtin_isfinite(v[i]) ? 0u : RMT_FLAG_NONFINITE;
     return f;
 }
 
@@ -496,7 +496,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_mem(
                         } else {
                             const real yn = ye[o] + h6 * a;
                             ye[o] = yn;
-                            flag |= (yn - yn == real(0)) ? 0u : RMT_FLAG_NONFINITE;
+                            flag |= __builtin_isfinite(yn) ? 0u : RMT_FLAG_NONFINITE;
                         }
                     }
                 }

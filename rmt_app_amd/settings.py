@@ -26,7 +26,7 @@ DEVICE_DEFAULTS = {
     "rk45-atol": 1e-9,
     "rk45-h0": 1e-6,
     "rk45-max-steps": 50_000_000,
-    "rk4-dt": 1e-5,
+    "rk4-dt": 2e-6,
 }
 
 ROUND_FUN_ACCURACY = 3   # PyREMOT/core/config.py:8-24 ("computation-time" rounding)

@@ -167,20 +167,52 @@ def test_flags_become_python_exceptions():
     dev.close()
 
 
-def test_rmtexe_rk4_end_to_end_vs_tight_scipy_reference():
+@pytest.mark.parametrize("name", ["dme_script", "dme_nb"])
+def test_rmtexe_rk4_end_to_end_vs_tight_scipy_reference(name):
     """BASELINE metric 'max |dMoFri| vs SciPy ref': rmtExe(hip-rk4) against the reference run
-    with LSODA/BDF at rtol<=1e-9 (golden G4), all five output times, outlet node."""
-    g = np.load(os.path.join(G, "g4_tight_dme_script_bdf.npz"))
-    mi = INP.dme_script_input(ivp="hip-rk4")
-    mi["solver-config"].update({"dt": 5e-6, "quiet": True})
+    with LSODA rtol=1e-10/atol=1e-12 (golden G4), all five output times.  The requirement is
+    <= 1e-6 relative on outlet mole fractions and temperature; measured ~5e-11, asserted 1e-8.
+    dt: the DME case needs dt <= ~3e-6 s once the bed is hot (DESIGN.md 'stability')."""
+    g = np.load(os.path.join(G, "g4_tight_%s_lsoda.npz" % name))
+    mi = INP.ALL_N2_INPUTS[name](ivp="hip-rk4")
+    mi["solver-config"].update({"dt": 2.5e-6, "quiet": True})
     res = rmtExe(mi)
     dp = res["resModel"]["dataPack"]
     assert len(dp) == solverSetting["N2"]["tNo"] == 5
-    worst = 0.0
+    worst = worst_all = 0.0
     for k in range(5):
-        a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
-        worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
+        a, b = dp[k]["dataYs"], g["dataYs_%d" % k]
+        worst = max(worst, np.max(np.abs(a[:, -1] - b[:, -1])/np.abs(b[:, -1])))
+        worst_all = max(worst_all, np.max(np.abs(a - b)/np.abs(b)))
         assert abs(dp[k]["dataTime"] - float(g["dataTime_%d" % k])) < 1e-12
-    assert worst < 1e-6, worst
-    full = np.max(np.abs(dp[4]["dataYs"] - g["dataYs_4"])/np.abs(g["dataYs_4"]))
-    assert full < 5e-6, full
+        for key in ("dataYCons1", "dataYCons2", "dataYTemp1", "dataYTemp2", "dataXs"):
+            assert np.shape(dp[k][key]) == g["%s_%d" % (key, k)].shape
+    assert worst < 1e-8, worst
+    assert worst_all < 1e-7, worst_all
+    assert res["resModel"]["device-stats"]["steps"] == 200000
+
+
+def test_rmtexe_reports_blowup_like_the_reference_raises():
+    """dt above the stability limit: the reference's own explicit path dies with OverflowError
+    inside a lambda; here the device flags come back as an exception."""
+    mi = INP.dme_script_input(ivp="hip-rk4")
+    mi["solver-config"].update({"dt": 1e-3, "quiet": True})
+    with pytest.raises((OverflowError, FloatingPointError, ValueError, ZeroDivisionError)):
+        rmtExe(mi)
+
+
+def test_rhs_near_steady_states_backward_stable():
+    """Mid-transient / near-steady states taken from the reference's tight LSODA run: every RHS
+    row is a small difference of large terms there, so parity is asserted as backward stability
+    (tests/parity.py) - the device result lies inside the oracle's own 1e-13 perturbation band
+    around the reference value."""
+    from parity import backward_ok
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["dme_script_20_transient_y"], g["dme_script_20_transient_f"]
+    mi, mech, _, dev = make_device("dme_script", 20, E=len(Y))
+    out = dev.rhs(dev.to_device(Y)).cpu().numpy()
+    fv = O.make_rhs_vec(O.setup_n2(mi, 20))
+    for k in range(len(Y)):
+        ok, d = backward_ok(out[k], F[k], fv, Y[k], 7)
+        assert ok, (k, d)
+    dev.close()

@@ -266,3 +266,40 @@ def test_result_packing_matches_reference_schema():
         np.testing.assert_allclose(d[key], g4[key + "_4"], rtol=1e-15, atol=0)
     assert d["labelList"] == INP.DME_COMPONENTS + ["Temperature"] and d["indexList"] == [6, 7, 6]
     assert d["dataShape"] == () and d["successStatus"] is True and d["modelId"] == "N2"
+
+
+@pytest.mark.parametrize("name", ["dme_script", "dme_nb"])
+def test_emulated_full_run_vs_tight_scipy_reference(name, template):
+    """Accuracy contract of the explicit stepper, checked on the CPU with the host build of the
+    generated source: RK4 dt=2.5e-6 s over the whole 0.5 s transient vs the reference integrated
+    by LSODA at rtol=1e-10 (golden G4): outlet <= 1e-8 relative (requirement: 1e-6)."""
+    g = np.load(os.path.join(G, "g4_tight_%s_lsoda.npz" % name))
+    mi = INP.ALL_N2_INPUTS[name]()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, 20)
+    emu = HostEmu(mech.source(template), tag=name)
+    y = plan.initial_state(nm, mech, 20)
+    worst = 0.0
+    for k in range(5):
+        y, fl = emu.rk4(y, row, 20, 2.5e-6, 40000)
+        y = y[0]
+        assert not fl.any()
+        d = pack_interval(y, nm, mech, 20, 0.1*(k + 1), "N2")
+        a, b = d["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
+        worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
+    assert worst < 1e-8, worst
+
+
+def test_generated_node_physics_near_steady_states(template):
+    from parity import backward_ok
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["dme_script_20_transient_y"], g["dme_script_20_transient_f"]
+    mi = INP.dme_script_input()
+    mech = plan.Mechanism(mi)
+    _, row = plan.member_constants(mi, mech, 20)
+    emu = HostEmu(mech.source(template), tag="dme_script")
+    out, flags = emu.rhs(Y, np.tile(row, (len(Y), 1)), 20)
+    fv = O.make_rhs_vec(O.setup_n2(mi, 20))
+    for k in range(len(Y)):
+        ok, d = backward_ok(out[k], F[k], fv, Y[k], 7)
+        assert ok, (k, d)

@@ -50,7 +50,7 @@ def sweep_member_inputs(first, count, total=2048):
     return out
 
 
-def cpu_baseline(mech, rows, IV, seconds=12.0):
+def cpu_baseline(mech, rows, IV, N_NODES, seconds=12.0):
     """The oracle side, timed on this box's host cores: host emulation of the same generated
     source (oracle/hostemu_driver.cpp, OpenMP over members) running the identical RK4."""
     from oracle.hostemu import HostEmu
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "reg", "mem"])
     ap.add_argument("--block", type=int, default=None)
     ap.add_argument("--npt", type=int, default=None)
+    ap.add_argument("--lds", type=int, default=None, help="RK4 vectors kept in LDS (0,1,2)")
     args = ap.parse_args()
 
     import torch
@@ -101,12 +102,11 @@ def main():
 
     from rmt_app_amd import plan
     from rmt_app_amd.n2 import N2Device
-    global N_NODES
-    N_NODES = args.nodes
+    n_nodes = args.nodes
     E = args.members
     inputs = sweep_member_inputs(rank*E, E, total=max(2048, world*E))
     mech = plan.Mechanism(inputs[0])
-    pairs = [plan.member_constants(mi, mech, N_NODES) for mi in inputs]
+    pairs = [plan.member_constants(mi, mech, n_nodes) for mi in inputs]
     rows = np.array([r for _, r in pairs])
     if distributed:
         # rank 0 owns the packed mechanism constants; broadcast over RCCL so every rank integrates
@@ -114,8 +114,8 @@ def main():
         tab = torch.tensor(np.concatenate([mech.nu.ravel(), mech.cp_coeff.ravel(), mech.StHeRe25]),
                            device="cuda")
         dist.broadcast(tab, src=0)
-    IV = np.array([plan.initial_state(nm, mech, N_NODES) for nm, _ in pairs])
-    dev = N2Device(mech, rows, N_NODES, block=args.block, npt=args.npt)
+    IV = np.array([plan.initial_state(nm, mech, n_nodes) for nm, _ in pairs])
+    dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds)
     dev.set_mode(args.mode)
     y = dev.to_device(IV)
 
@@ -139,34 +139,34 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
     # outlet rows (mole fractions need concentrations only) gathered for the record
-    outlet = y.reshape(E, mech.V, N_NODES)[:, :, -1].contiguous()
+    outlet = y.reshape(E, mech.V, n_nodes)[:, :, -1].contiguous()
     if distributed:
         gathered = [torch.empty_like(outlet) for _ in range(world)] if rank == 0 else None
         dist.gather(outlet, gathered, dst=0)
 
     if rank == 0:
-        node_steps = world*E*N_NODES*args.steps
+        node_steps = world*E*n_nodes*args.steps
         value = node_steps/tmax
         bytes_per_node_step = 2*(mech.S + 2)*8
-        achieved = (E*N_NODES*args.steps*bytes_per_node_step/1e9)/(kernel_ms/1e3)
+        achieved = (E*n_nodes*args.steps*bytes_per_node_step/1e9)/(kernel_ms/1e3)
         line = {
             "metric": "mesh-node-steps/s (6-sp DME dynamic model)",
             "value": value, "unit": "mesh-node-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3*tmax/args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "DME N2 (TEST2.ipynb reactor), %d nodes, RK4 dt=2e-6 s, %d "
-                                   "reactors/GPU of the 64x32 inlet-T/P sweep" % (N_NODES, E),
-                       "members_per_gpu": E, "nodes": N_NODES, "integrator": "rk4",
+                                   "reactors/GPU of the 64x32 inlet-T/P sweep" % (n_nodes, E),
+                       "members_per_gpu": E, "nodes": n_nodes, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,
-                       "kernel": "rmt_n2_rk4_%s block=%d npt=%d" % (
-                           "reg" if (args.mode != "mem" and N_NODES <= dev.block*dev.npt) else "mem",
-                           dev.block, dev.npt)},
+                       "kernel": "rmt_n2_rk4_%s block=%d npt=%d lds_state=%d" % (
+                           "reg" if (args.mode != "mem" and n_nodes <= dev.block*dev.npt) else "mem",
+                           dev.block, dev.npt, dev.lds_state)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved/HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step},
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(mech, rows, IV)
+            line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)
         print(json.dumps(line))
     dev.close()
     if distributed:

@@ -7,9 +7,8 @@ R"RMTSRC(// ====================================================================
 //   RMT_NPT                 nodes per thread of the register-resident steppers
 //   typedef ... real;       double or float
 //   RMT_MW[S]               molecular weights [g/mol]
-//   RMT_CP[S][4]            Cp(T) = a + b T + c T^2 + d T^3  [J/mol/K]
-//   RMT_CPREF[S]            Cp(Tref)
-//   RMT_NU[R][S]            stoichiometric matrix (sum over all occurrences of a species)
+//   rmt_species_source(r,s) s = nu^T r, rmt_reaction_dcp(cp,d) d = nu cp   (sparse, unrolled)
+//   rmt_cp_mean(i,T)        0.5*(Cp_i(Tref)+Cp_i(T)) with only the non-zero polynomial terms
 //   RMT_DH25[R]             standard heats of reaction [J/mol]
 //   rmt_kinetics(T,P,x,C,r,flag)   lowered user rate lambdas
 //
@@ -64,7 +63,6 @@ __device__ __forceinline__ double rmt_exp(double x) { return exp(x); }
 __device__ __forceinline__ double rmt_exp10(double x) { return exp10(x); }
 __device__ __forceinline__ double rmt_exp2(double x) { return exp2(x); }
 __device__ __forceinline__ double rmt_expm1(double x) { return expm1(x); }
-__device__ __forceinline__ double rmt_log(double x) { return log(x); }
 __device__ __forceinline__ double rmt_log10(double x) { return log10(x); }
 __device__ __forceinline__ double rmt_log2(double x) { return log2(x); }
 __device__ __forceinline__ double rmt_log1p(double x) { return log1p(x); }
@@ -100,6 +98,51 @@ __device__ __forceinline__ float rmt_cosh(float x) { return coshf(x); }
 __device__ __forceinline__ float rmt_atan(float x) { return atanf(x); }
 __device__ __forceinline__ float rmt_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float rmt_max(float a, float b) { return fmaxf(a, b); }
+
+// ---- lean fp64 division / reciprocal / log (RMT_FAST_MATH, default on) -----------------------
+// gfx950 costs in fp64 VALU ops (llvm-objdump of the ocml versions): x/y 11 (+v_rcp_f64), log 76,
+// log10 83, exp 19, sqrt 14.  The versions below drop the scale/fixup and double-double work that
+// only matters for denormal/huge operands or the last half ulp: rcp 5, div 8, log ~30 ops, each
+// accurate to ~1 ulp on normal numbers - far inside the 1e-12 parity budget of the RHS.
+#ifndef RMT_FAST_MATH
+#define RMT_FAST_MATH 1
+#endif
+#if RMT_FAST_MATH && !defined(RMT_HOST_EMULATION)
+__device__ __forceinline__ double rmt_rcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rmt_div(double a, double b) {
+    const double r = rmt_rcp(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double rmt_log(double x) {     // after fdlibm e_log.c (x > 0, finite)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    double m = __builtin_amdgcn_frexp_mant(x);            // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = rmt_div(f, 2.0 + f);
+    const double dk = (double)e;
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+#else
+__device__ __forceinline__ double rmt_rcp(double b) { return 1.0 / b; }
+__device__ __forceinline__ double rmt_div(double a, double b) { return a / b; }
+__device__ __forceinline__ double rmt_log(double x) { return log(x); }
+#endif
+__device__ __forceinline__ float rmt_rcp(float b) { return 1.0f / b; }
+__device__ __forceinline__ float rmt_div(float a, float b) { return a / b; }
 
 template <typename T>
 __device__ __forceinline__ unsigned rmt_pow_flags(T x, T y) {
@@ -156,7 +199,7 @@ __device__ __forceinline__ preal rmt_node_pre(const RmtMember& m, const real* __
         nd.C[i] = cc * m.cmax;                            // :3903 (MAX scaling)
         ctot += nd.C[i];
     }
-    const real inv_ctot = real(1) / ctot;
+    const real inv_ctot = rmt_rcp(ctot);
     real mw = real(0);
 #pragma unroll
     for (int i = 0; i < RMT_S; ++i) {
@@ -170,7 +213,7 @@ __device__ __forceinline__ preal rmt_node_pre(const RmtMember& m, const real* __
     nd.T = ys[RMT_S] * m.tf + m.tf;                       // :3914
 #endif
     // P[z+1] = P[z] + dz*(-(ergA*ergB + 1.75*rho*v^2/dp*ergD)),  rho = P*M/(R*T)   (:3964-3979)
-    return preal(1) - m.alpha_k * (preal(nd.M) / preal(nd.T));
+    return preal(1) - m.alpha_k * rmt_div(preal(nd.M), preal(nd.T));
 }
 
 // Phase B (pressure known): kinetics, species source, Cp, heat of reaction, wall exchange,
@@ -182,13 +225,12 @@ __device__ __forceinline__ void rmt_node_post(const RmtMember& m, const RmtNode&
     const real P = real(Pz);
     real r[RMT_R];
     rmt_kinetics(nd.T, P, nd.x, nd.C, r, flag);           // :3989-3992
+    real src[RMT_S];
+    rmt_species_source(r, src);                                         // :4000 (sparse nu^T r)
 #pragma unroll
     for (int i = 0; i < RMT_S; ++i) {
-        real s = real(0);
-#pragma unroll
-        for (int q = 0; q < RMT_R; ++q) s += RMT_NU[q][i] * r[q];       // :4000
         const real dcdz = (ys[i] - up[i]) * m.inv_dz;                   // :4086-4095
-        k[i] = m.f1 * (s * m.inv_macote - dcdz);                        // :4098
+        k[i] = m.f1 * (src[i] * m.inv_macote - dcdz);                   // :4098
     }
 #if !RMT_ISO
     const real T = nd.T;
@@ -196,24 +238,20 @@ __device__ __forceinline__ void rmt_node_post(const RmtMember& m, const RmtNode&
     real cpm = real(0);
 #pragma unroll
     for (int i = 0; i < RMT_S; ++i) {
-        const real cpT = RMT_CP[i][0] + RMT_CP[i][1] * T + RMT_CP[i][2] * (T * T)
-                       + RMT_CP[i][3] * (T * T * T);
-        cpbar[i] = (RMT_CPREF[i] + cpT) * real(0.5);                    // rmtThermo.py:52-75
+        cpbar[i] = rmt_cp_mean(i, T);                                   // rmtThermo.py:52-75
         cpm += nd.x[i] * cpbar[i];                                      // :4013
     }
+    real dcp[RMT_R];
+    rmt_reaction_dcp(cpbar, dcp);                                       // sparse nu cpbar
     real qr = real(0);
 #pragma unroll
-    for (int q = 0; q < RMT_R; ++q) {
-        real dcp = real(0);
-#pragma unroll
-        for (int i = 0; i < RMT_S; ++i) dcp += RMT_NU[q][i] * cpbar[i];
-        qr += r[q] * (dcp * (T - RMT_TREF) + RMT_DH25[q]);              // :4025-4032
-    }
+    for (int q = 0; q < RMT_R; ++q)
+        qr += r[q] * (dcp[q] * (T - RMT_TREF) + RMT_DH25[q]);           // :4025-4032
     const real qm = (m.tm == real(0)) ? real(0) : m.ua * (m.tm - T);    // rmtUtility.py:438-445
-    const real rho_s = (P * nd.M / T) * m.rho_k;                        // :3964-3966
+    const real rho_s = rmt_div(P * nd.M, T) * m.rho_k;                  // :3964-3966
     const real cp_s = cpm * m.inv_cp0;                                  // :4016
     const real dtdz = (ys[RMT_S] - up[RMT_S]) * m.inv_dz;               // :4104-4114
-    k[RMT_S] = m.f1 * ((qm - qr) * m.inv_hecote) / (rho_s * cp_s) - m.ft * dtdz;   // :4116-4126
+    k[RMT_S] = rmt_div(m.f1 * ((qm - qr) * m.inv_hecote), rho_s * cp_s) - m.ft * dtdz;   // :4116-4126
 #endif
 }
 
@@ -385,14 +423,28 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rhs(
     if (flag) atomicOr(&flags[e], flag);
 }
 
-// ===================================================================== kernel: RK4, state in registers
+// ===================================================================== kernel: RK4, state on chip
 // nsteps classic RK4 steps of size h (tableau and update order of odeSolver.py:17-40) for reactor
-// e = blockIdx.x with N <= RMT_BLOCK*RMT_NPT nodes.  The state is read once, kept in VGPRs for
-// all steps, and written once: HBM traffic is 2*V*sizeof(real) per node per LAUNCH.
+// e = blockIdx.x with N <= RMT_BLOCK*RMT_NPT nodes.  The state is read from HBM once, kept on
+// chip for all steps and written once: HBM traffic is 2*V*sizeof(real) per node per LAUNCH.
+// RMT_LDS_STATE selects where the two long-lived RK4 vectors live (only the stage input and the
+// current K are always in VGPRs):  2 = y_n and the K accumulator in LDS,  1 = y_n in LDS,
+// 0 = both in VGPRs.  Each thread only touches its own nodes' LDS slots, so no barrier is needed.
+#ifndef RMT_LDS_STATE
+#define RMT_LDS_STATE 0
+#endif
+#define RMT_NODES_WG (RMT_BLOCK * RMT_NPT)
+
 extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
         real* __restrict__ y, const double* __restrict__ members, const int N, const double h_,
         const long long nsteps, unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+#if RMT_LDS_STATE >= 1
+    __shared__ real s_y0[RMT_V][RMT_NODES_WG];
+#endif
+#if RMT_LDS_STATE >= 2
+    __shared__ real s_acc[RMT_V][RMT_NODES_WG];
+#endif
     const int e = blockIdx.x;
     RmtMember m;
     rmt_load_member(members + (size_t)e * RMT_NM, m);
@@ -402,48 +454,68 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
     const int node0 = (int)threadIdx.x * RMT_NPT;
     int nvalid = N - node0;
     nvalid = nvalid < 0 ? 0 : (nvalid > RMT_NPT ? RMT_NPT : nvalid);
-    real y0[RMT_NPT][RMT_V], ys[RMT_NPT][RMT_V], acc[RMT_NPT][RMT_V], k[RMT_NPT][RMT_V];
+    real ys[RMT_NPT][RMT_V], k[RMT_NPT][RMT_V];
+#if RMT_LDS_STATE < 1
+    real y0[RMT_NPT][RMT_V];
+#define Y0(j, i) y0[j][i]
+#else
+#define Y0(j, i) s_y0[i][node0 + (j)]
+#endif
+#if RMT_LDS_STATE < 2
+    real acc[RMT_NPT][RMT_V];
+#define ACC(j, i) acc[j][i]
+#else
+#define ACC(j, i) s_acc[i][node0 + (j)]
+#endif
 #pragma unroll
     for (int j = 0; j < RMT_NPT; ++j) {
-        rmt_safe_state(m, y0[j]);
+        rmt_safe_state(m, ys[j]);
         if (j < nvalid) {
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) y0[j][i] = ye[(size_t)i * N + node0 + j];
+            for (int i = 0; i < RMT_V; ++i) ys[j][i] = ye[(size_t)i * N + node0 + j];
         }
+#pragma unroll
+        for (int i = 0; i < RMT_V; ++i) Y0(j, i) = ys[j][i];
     }
     const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
     unsigned flag = 0u;
     for (long long step = 0; step < nsteps; ++step) {
-        rmt_rhs_block<RMT_NPT, false>(m, sh, 0, y0, nvalid, carry, k, flag);          // K1 = f(y)
+        rmt_rhs_block<RMT_NPT, false>(m, sh, 0, ys, nvalid, carry, k, flag);          // K1 = f(y)
 #pragma unroll
         for (int j = 0; j < RMT_NPT; ++j)
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) { acc[j][i] = k[j][i]; ys[j][i] = y0[j][i] + k[j][i] * hh; }
+            for (int i = 0; i < RMT_V; ++i) { ACC(j, i) = k[j][i]; ys[j][i] = Y0(j, i) + k[j][i] * hh; }
         rmt_rhs_block<RMT_NPT, false>(m, sh, 1, ys, nvalid, carry, k, flag);          // K2 = f(y+K1 h/2)
 #pragma unroll
         for (int j = 0; j < RMT_NPT; ++j)
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) { acc[j][i] += real(2) * k[j][i]; ys[j][i] = y0[j][i] + k[j][i] * hh; }
+            for (int i = 0; i < RMT_V; ++i) { ACC(j, i) += real(2) * k[j][i]; ys[j][i] = Y0(j, i) + k[j][i] * hh; }
         rmt_rhs_block<RMT_NPT, false>(m, sh, 0, ys, nvalid, carry, k, flag);          // K3 = f(y+K2 h/2)
 #pragma unroll
         for (int j = 0; j < RMT_NPT; ++j)
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) { acc[j][i] += real(2) * k[j][i]; ys[j][i] = y0[j][i] + k[j][i] * h; }
+            for (int i = 0; i < RMT_V; ++i) { ACC(j, i) += real(2) * k[j][i]; ys[j][i] = Y0(j, i) + k[j][i] * h; }
         rmt_rhs_block<RMT_NPT, false>(m, sh, 1, ys, nvalid, carry, k, flag);          // K4 = f(y+K3 h)
 #pragma unroll
         for (int j = 0; j < RMT_NPT; ++j)
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) y0[j][i] += h6 * (acc[j][i] + k[j][i]);   // y + h(K1+2K2+2K3+K4)/6
+            for (int i = 0; i < RMT_V; ++i) {                                         // y + h(K1+2K2+2K3+K4)/6
+                const real yn = Y0(j, i) + h6 * (ACC(j, i) + k[j][i]);
+                Y0(j, i) = yn;
+                ys[j][i] = yn;
+            }
     }
 #pragma unroll
     for (int j = 0; j < RMT_NPT; ++j) {
         if (j < nvalid) {
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) ye[(size_t)i * N + node0 + j] = y0[j][i];
-            flag |= rmt_finite_flag(y0[j]);
+            for (int i = 0; i < RMT_V; ++i) ye[(size_t)i * N + node0 + j] = ys[j][i];
+            flag |= rmt_finite_flag(ys[j]);
         }
     }
     if (flag) atomicOr(&flags[e], flag);
+#undef Y0
+#undef ACC
 }
 
 // ===================================================================== kernel: RK4, state in memory

@@ -380,9 +380,87 @@ class Lowered:
                           "min": lambda: min(u, v), "max": lambda: max(u, v)}[op]()
             else:
                 fn = {"neg": lambda u: -u, "abs": abs, "exp10": lambda u: 10.0**u,
-                      "exp2": lambda u: 2.0**u}.get(op) or getattr(math, op)
+                      "exp2": lambda u: 2.0**u, "rcp": lambda u: 1.0/u,
+                      "expn": lambda u: math.exp(-u), "exp10n": lambda u: 10.0**(-u),
+                      "exp2n": lambda u: 2.0**(-u)}.get(op) or getattr(math, op)
                 env[i] = fn(env[a])
         return [env[o] for o in self.outputs]
+
+    # ---- algebraic strength reduction (device build only; changes results by a few ulp)
+    def optimize(self):
+        """Cheaper but equivalent forms for the fp64 VALU (costs measured on gfx950):
+          a/exp(z)           -> a*exp(-z)            when exp(z) is only ever a divisor
+          a/b, c/b, ...      -> a*r, c*r, r = 1/b    when b divides at least twice
+          log10(x)           -> log(x)*(1/ln 10)     (one log serves both bases)
+        The Python-exception conditions of the original expressions are still flagged."""
+        g = self.g
+        uses = {}          # node -> list of (user, slot)
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op in ("const", "in"):
+                continue
+            uses.setdefault(a, []).append((i, 0))
+            if b is not None and op != "powi":
+                uses.setdefault(b, []).append((i, 1))
+        for o in self.outputs:
+            uses.setdefault(o, []).append((-1, 0))
+        def only_divides(n):
+            return bool(uses.get(n)) and all(u >= 0 and g.nodes[u][0] == "div" and slot == 1
+                                             for (u, slot) in uses[n])
+        # b "divides" directly (x/b) or through an integer power that itself only divides (x/b^n)
+        div_uses = {}
+        for n, us in uses.items():
+            c = 0
+            for (u, slot) in us:
+                if u < 0:
+                    continue
+                uop = g.nodes[u][0]
+                if uop == "div" and slot == 1:
+                    c += 1
+                elif uop == "powi" and g.nodes[u][2] > 0 and only_divides(u):
+                    c += len(uses[u])
+            div_uses[n] = c
+        g2 = Graph()
+        new = {}
+        LOG10E = 1.0/math.log(10.0)
+        NEGEXP = {"exp": "expn", "exp10": "exp10n", "exp2": "exp2n"}
+
+        def mul(x, y):
+            return x._bin("mul", x, y, lambda p, q: p*q)
+
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op == "const":
+                new[i] = g2.const(g.cval(i))
+            elif op == "in":
+                new[i] = g2.inp(a)
+            elif op == "powi":
+                new[i] = None if (b > 0 and only_divides(i) and div_uses.get(a, 0) >= 2
+                                  and not g.is_const(a)) else g2._mk("powi", new[a].i, b)
+            elif op == "div":
+                bop, ba, bb = g.nodes[b]
+                if bop in NEGEXP and only_divides(b):
+                    new[i] = mul(new[a], g2._mk(NEGEXP[bop], new[ba].i))
+                elif bop == "powi" and new[b] is None:
+                    r = g2._mk("rcp", new[ba].i)
+                    new[i] = mul(new[a], g2._mk("powi", r.i, bb))
+                elif div_uses.get(b, 0) >= 2 and not g.is_const(b):
+                    new[i] = mul(new[a], g2._mk("rcp", new[b].i))
+                else:
+                    new[i] = g2._mk("div", new[a].i, new[b].i)
+            elif op == "log10":
+                lg = g2._mk("log", new[a].i)
+                new[i] = mul(lg, g2.const(LOG10E))
+            elif op in NEGEXP and only_divides(i):
+                new[i] = None          # 1/exp(z) is emitted as exp(-z) at its uses
+            elif b is None:
+                new[i] = g2._mk(op, new[a].i)
+            else:
+                x, y = new[a].i, new[b].i
+                if op in ("add", "mul", "min", "max") and x > y:
+                    x, y = y, x
+                new[i] = g2._mk(op, x, y)
+        return Lowered(g2, [new[o].i for o in self.outputs], self.S)
 
     # ---- HIP C++ emission
     def emit(self, fname="rmt_kinetics"):
@@ -419,7 +497,19 @@ class Lowered:
                 e = "%s * %s" % (A, B)
             elif op == "div":
                 pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (B, FLAG_DIV0))
-                e = "%s / %s" % (A, B)
+                e = "rmt_div(%s, %s)" % (A, B)
+            elif op == "rcp":
+                pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (A, FLAG_DIV0))
+                e = "rmt_rcp(%s)" % A
+            elif op == "expn":      # stands for 1/exp(A): Python raises if exp(A) overflows or is 0
+                pre.append("flag |= (%s > real(%r)) ? %du : 0u;" % (A, _EXP_MAX, FLAG_OVERFLOW))
+                pre.append("flag |= (%s < real(%r)) ? %du : 0u;" % (A, -745.1332191019411, FLAG_DIV0))
+                e = "rmt_exp(-%s)" % A
+            elif op in ("exp10n", "exp2n"):
+                lim = {"exp10n": 308.2547155599167, "exp2n": 1024.0}[op]
+                pre.append("flag |= (%s > real(%r)) ? %du : 0u;" % (A, lim, FLAG_OVERFLOW))
+                pre.append("flag |= (%s < real(%r)) ? %du : 0u;" % (A, -lim - 15.0, FLAG_DIV0))
+                e = "rmt_%s(-%s)" % (op[:-1], A)
             elif op == "neg":
                 e = "-%s" % A
             elif op == "abs":

@@ -88,6 +88,8 @@ def wilke(visc, x, MW):
 class Mechanism:
     """Ensemble-invariant part of a model: becomes literals in the generated kernel."""
 
+    optimize = True     # class-wide switch: emit the strength-reduced kinetics DAG
+
     def __init__(self, modelInput):
         mi = modelInput
         self.compList = list(mi['feed']['components']['shell'])
@@ -129,7 +131,7 @@ class Mechanism:
         return (hp - hr)*1000.00
 
     # ------------------------------------------------------------------ kernel source
-    def prelude(self, fp32=False, block=1024, npt=1):
+    def prelude(self, fp32=False, block=1024, npt=1, lds_state=None):
         def arr(vals):
             return "{" + ", ".join("real(%r)" % float(v) for v in vals) + "}"
         S, R = self.S, self.R
@@ -141,27 +143,72 @@ class Mechanism:
             "#define RMT_FP32 %d" % (1 if fp32 else 0),
             "#define RMT_BLOCK %d" % block,
             "#define RMT_NPT %d" % npt,
+            "#define RMT_LDS_STATE %d" % self.lds_state(fp32, block, npt, lds_state),
             "typedef %s real;" % ("float" if fp32 else "double"),
             "__device__ static const real RMT_MW[RMT_S] = %s;" % arr(self.MW),
-            "__device__ static const real RMT_CP[RMT_S][4] = {%s};" % ", ".join(
-                arr(row) for row in self.cp_coeff),
-            "__device__ static const real RMT_CPREF[RMT_S] = %s;" % arr(self.cp_ref),
-            "__device__ static const real RMT_NU[RMT_R][RMT_S] = {%s};" % ", ".join(
-                arr(row) for row in self.nu),
             "__device__ static const real RMT_DH25[RMT_R] = %s;" % arr(self.StHeRe25),
         ]
+
+        def lincomb(coeffs, name):
+            terms = []
+            for idx, c in enumerate(coeffs):
+                if c == 0:
+                    continue
+                mag = "%s[%d]" % (name, idx) if abs(c) == 1 else "real(%r) * %s[%d]" % (abs(float(c)), name, idx)
+                terms.append((" - " if c < 0 else " + ") + mag)
+            if not terms:
+                return "real(0)"
+            out = "".join(terms)
+            return out[3:] if out.startswith(" + ") else "-" + out[3:]
+
+        lines.append("__device__ __forceinline__ void rmt_species_source(const real* __restrict__ r, "
+                     "real* __restrict__ s) {")
+        for i in range(S):
+            lines.append("    s[%d] = %s;" % (i, lincomb(self.nu[:, i], "r")))
+        lines.append("}")
+        lines.append("__device__ __forceinline__ void rmt_reaction_dcp(const real* __restrict__ c, "
+                     "real* __restrict__ d) {")
+        for k in range(R):
+            lines.append("    d[%d] = %s;" % (k, lincomb(self.nu[k, :], "c")))
+        lines.append("}")
+        lines.append("__device__ __forceinline__ real rmt_cp_mean(const int i, const real T) {")
+        lines.append("    const real T2 = T * T;")
+        for i in range(S):
+            a, b, c, d = (float(v) for v in self.cp_coeff[i])
+            e = "real(%r) + real(%r) * T" % (a, b)
+            if c != 0.0:
+                e += " + real(%r) * T2" % c
+            if d != 0.0:
+                e += " + real(%r) * (T2 * T)" % d
+            lines.append("    if (i == %d) return (real(%r) + (%s)) * real(0.5);" % (i, float(self.cp_ref[i]), e))
+        lines.append("    return real(0);")
+        lines.append("}")
         return "\n".join(lines) + "\n"
 
-    def source(self, template, fp32=False, block=1024, npt=1):
+    def device_dag(self):
+        """The DAG that is printed for the device: the traced one after strength reduction
+        (lowering.Lowered.optimize); ``self.lowered`` stays the bit-exact trace."""
+        if getattr(self, "_opt", None) is None:
+            self._opt = self.lowered.optimize() if self.optimize else self.lowered
+        return self._opt
+
+    def lds_state(self, fp32, block, npt, want=None):
+        """How many of the two long-lived RK4 vectors (y_n, K accumulator) the on-chip stepper
+        keeps in LDS instead of VGPRs: as many as fit in 144 KiB of the CU's 160 KiB."""
+        per = self.V*block*npt*(4 if fp32 else 8)
+        fit = min(2, (144*1024)//per)
+        return fit if want is None else min(int(want), fit)
+
+    def source(self, template, fp32=False, block=1024, npt=1, lds_state=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
         if "RMT_KINETICS_SOURCE" not in template:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
-        body = template.replace("RMT_KINETICS_SOURCE", self.lowered.emit("rmt_kinetics"), 1)
-        return self.prelude(fp32, block, npt) + body
+        body = template.replace("RMT_KINETICS_SOURCE", self.device_dag().emit("rmt_kinetics"), 1)
+        return self.prelude(fp32, block, npt, lds_state) + body
 
-    def digest(self, template, fp32, block, npt):
+    def digest(self, template, fp32, block, npt, lds_state=None):
         h = hashlib.sha256()
-        h.update(self.source(template, fp32, block, npt).encode())
+        h.update(self.source(template, fp32, block, npt, lds_state).encode())
         return h.hexdigest()[:24]
 
 

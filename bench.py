@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--block", type=int, default=None)
     ap.add_argument("--npt", type=int, default=None)
     ap.add_argument("--lds", type=int, default=None, help="RK4 vectors kept in LDS (0,1,2)")
+    ap.add_argument("--define", action="append", default=[], help="kernel tuning macro NAME=VALUE")
     args = ap.parse_args()
 
     import torch
@@ -115,7 +116,8 @@ def main():
                            device="cuda")
         dist.broadcast(tab, src=0)
     IV = np.array([plan.initial_state(nm, mech, n_nodes) for nm, _ in pairs])
-    dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds)
+    dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds,
+                   defines=dict(d.split('=', 1) for d in args.define))
     dev.set_mode(args.mode)
     y = dev.to_device(IV)
 

@@ -26,6 +26,12 @@ R"RMTSRC(// ====================================================================
 // =====================================================================================
 
 #define RMT_V (RMT_S + (RMT_ISO ? 0 : 1))
+#ifndef RMT_MEMBER_LDS
+#define RMT_MEMBER_LDS 0
+#endif
+#ifndef RMT_STAGE_UNROLL
+#define RMT_STAGE_UNROLL 1
+#endif
 #define RMT_NW (RMT_BLOCK / 64)
 #define RMT_NM (16 + RMT_S)
 
@@ -99,6 +105,36 @@ __device__ __forceinline__ float rmt_atan(float x) { return atanf(x); }
 __device__ __forceinline__ float rmt_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float rmt_max(float a, float b) { return fmaxf(a, b); }
 
+// ---- status flags ---------------------------------------------------------------------------
+// The generated kinetics test the conditions on which Python would raise (log(<=0), x/0, exp
+// overflow ...).  On the device each test is one v_cmp into an SGPR pair that is OR-ed into a
+// wave-wide lane mask with a scalar instruction (no per-lane select/or VALU work); the masks
+// are collapsed to the per-reactor status bits once, at the end of the launch.
+#ifdef RMT_HOST_EMULATION
+typedef unsigned rmt_flags_t;
+#define RMT_CHECK(f, cond, bit) (f) |= ((cond) ? (bit) : 0u)
+#else
+struct rmt_flags_t { unsigned long long dom, div0, ovf; };
+template <unsigned BIT>
+__device__ __forceinline__ void rmt_check(rmt_flags_t& f, const bool c) {
+    const unsigned long long m = __ballot(c);
+    if (BIT == RMT_FLAG_DOMAIN) f.dom |= m;
+    else if (BIT == RMT_FLAG_DIV0) f.div0 |= m;
+    else f.ovf |= m;
+}
+#define RMT_CHECK(f, cond, bit) rmt_check<bit>(f, (cond))
+__device__ __forceinline__ void rmt_flags_clear(rmt_flags_t& f) { f.dom = f.div0 = f.ovf = 0ull; }
+__device__ __forceinline__ void rmt_flags_merge(rmt_flags_t& into, const rmt_flags_t& f,
+                                                const unsigned long long lanes) {
+    into.dom |= f.dom & lanes;
+    into.div0 |= f.div0 & lanes;
+    into.ovf |= f.ovf & lanes;
+}
+__device__ __forceinline__ unsigned rmt_flags_bits(const rmt_flags_t& f) {
+    return (f.dom ? RMT_FLAG_DOMAIN : 0u) | (f.div0 ? RMT_FLAG_DIV0 : 0u) | (f.ovf ? RMT_FLAG_OVERFLOW : 0u);
+}
+#endif
+
 // ---- lean fp64 division / reciprocal / log (RMT_FAST_MATH, default on) -----------------------
 // gfx950 costs in fp64 VALU ops (llvm-objdump of the ocml versions): x/y 11 (+v_rcp_f64), log 76,
 // log10 83, exp 19, sqrt 14.  The versions below drop the scale/fixup and double-double work that
@@ -143,14 +179,6 @@ __device__ __forceinline__ double rmt_log(double x) { return log(x); }
 #endif
 __device__ __forceinline__ float rmt_rcp(float b) { return 1.0f / b; }
 __device__ __forceinline__ float rmt_div(float a, float b) { return a / b; }
-
-template <typename T>
-__device__ __forceinline__ unsigned rmt_pow_flags(T x, T y) {
-    unsigned f = 0u;
-    if (x < T(0) && y != trunc(y)) f |= RMT_FLAG_DOMAIN;
-    if (x == T(0) && y < T(0)) f |= RMT_FLAG_DIV0;
-    return f;
-}
 
 RMT_KINETICS_SOURCE
 
@@ -221,7 +249,7 @@ __device__ __forceinline__ preal rmt_node_pre(const RmtMember& m, const real* __
 __device__ __forceinline__ void rmt_node_post(const RmtMember& m, const RmtNode& nd,
                                               const real* __restrict__ ys,
                                               const real* __restrict__ up, const preal Pz,
-                                              real* __restrict__ k, unsigned& flag) {
+                                              real* __restrict__ k, rmt_flags_t& flag) {
     const real P = real(Pz);
     real r[RMT_R];
     rmt_kinetics(nd.T, P, nd.x, nd.C, r, flag);           // :3989-3992
@@ -293,7 +321,7 @@ template <int NPT, bool CARRY_OUT>
 __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh, const int buf,
                                               const real (&ys)[NPT][RMT_V], const int nvalid,
                                               RmtCarry& carry, real (&k)[NPT][RMT_V],
-                                              unsigned& flag) {
+                                              rmt_flags_t& flag) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     RmtNode nd[NPT];
@@ -351,9 +379,8 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
     preal P = exc.a * pw + exc.b;
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
-        unsigned f = 0u;
-        rmt_node_post(m, nd[j], ys[j], up, P, k[j], f);
-        if (j < nvalid) flag |= f;
+        // lanes beyond the reactor's end carry the (valid) inlet state, so their checks are not masked
+        rmt_node_post(m, nd[j], ys[j], up, P, k[j], flag);
         P = loc[j].a * P + loc[j].b;
         if (j + 1 < NPT) {
 #pragma unroll
@@ -396,13 +423,21 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rhs(
         const int N, unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
     const int e = blockIdx.x;
+#if RMT_MEMBER_LDS
+    __shared__ RmtMember m;      // read back with broadcast ds_reads: frees ~2*(15+S) SGPRs
+    if (threadIdx.x == 0) rmt_load_member(members + (size_t)e * RMT_NM, m);
+    __syncthreads();
+#else
     RmtMember m;
     rmt_load_member(members + (size_t)e * RMT_NM, m);
+#endif
     RmtCarry carry;
     rmt_carry_inlet(m, carry);
     const real* ye = y + (size_t)e * RMT_V * N;
     real* de = dydt + (size_t)e * RMT_V * N;
-    unsigned flag = 0u;
+    rmt_flags_t flag;
+    rmt_flags_clear(flag);
+    unsigned lflag = 0u;
     int ph = 0;
     for (int base = 0; base < N; base += RMT_BLOCK, ph ^= 1) {
         const int node = base + (int)threadIdx.x;
@@ -417,10 +452,11 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rhs(
         if (valid) {
 #pragma unroll
             for (int i = 0; i < RMT_V; ++i) de[(size_t)i * N + node] = k[0][i];
-            flag |= rmt_finite_flag(k[0]);
+            lflag |= rmt_finite_flag(k[0]);
         }
     }
-    if (flag) atomicOr(&flags[e], flag);
+    lflag |= rmt_flags_bits(flag);
+    if (lflag) atomicOr(&flags[e], lflag);
 }
 
 // ===================================================================== kernel: RK4, state on chip
@@ -446,8 +482,14 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
     __shared__ real s_acc[RMT_V][RMT_NODES_WG];
 #endif
     const int e = blockIdx.x;
+#if RMT_MEMBER_LDS
+    __shared__ RmtMember m;      // read back with broadcast ds_reads: frees ~2*(15+S) SGPRs
+    if (threadIdx.x == 0) rmt_load_member(members + (size_t)e * RMT_NM, m);
+    __syncthreads();
+#else
     RmtMember m;
     rmt_load_member(members + (size_t)e * RMT_NM, m);
+#endif
     RmtCarry carry;
     rmt_carry_inlet(m, carry);
     real* ye = y + (size_t)e * RMT_V * N;
@@ -478,42 +520,51 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
         for (int i = 0; i < RMT_V; ++i) Y0(j, i) = ys[j][i];
     }
     const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
-    unsigned flag = 0u;
+    rmt_flags_t flag;
+    rmt_flags_clear(flag);
+    unsigned lflag = 0u;
     for (long long step = 0; step < nsteps; ++step) {
-        rmt_rhs_block<RMT_NPT, false>(m, sh, 0, ys, nvalid, carry, k, flag);          // K1 = f(y)
+        // One copy of the RHS code serves the four stages (a fully unrolled step is ~64 KB of
+        // instructions - the size of the instruction cache); s is wave-uniform.
+#if RMT_STAGE_UNROLL
 #pragma unroll
-        for (int j = 0; j < RMT_NPT; ++j)
+#else
+#pragma unroll 1
+#endif
+        for (int s = 0; s < 4; ++s) {
+            rmt_rhs_block<RMT_NPT, false>(m, sh, s & 1, ys, nvalid, carry, k, flag);  // K_{s+1} = f(ys)
+            if (s < 3) {
+                const real cn = (s == 2) ? h : hh;                // stage inputs y+K1 h/2, y+K2 h/2, y+K3 h
+                const real wk = (s == 0) ? real(1) : real(2);     // weights 1,2,2,(1)
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) { ACC(j, i) = k[j][i]; ys[j][i] = Y0(j, i) + k[j][i] * hh; }
-        rmt_rhs_block<RMT_NPT, false>(m, sh, 1, ys, nvalid, carry, k, flag);          // K2 = f(y+K1 h/2)
+                for (int j = 0; j < RMT_NPT; ++j)
 #pragma unroll
-        for (int j = 0; j < RMT_NPT; ++j)
+                    for (int i = 0; i < RMT_V; ++i) {
+                        ACC(j, i) = (s == 0) ? k[j][i] : ACC(j, i) + wk * k[j][i];
+                        ys[j][i] = Y0(j, i) + k[j][i] * cn;
+                    }
+            } else {
 #pragma unroll
-            for (int i = 0; i < RMT_V; ++i) { ACC(j, i) += real(2) * k[j][i]; ys[j][i] = Y0(j, i) + k[j][i] * hh; }
-        rmt_rhs_block<RMT_NPT, false>(m, sh, 0, ys, nvalid, carry, k, flag);          // K3 = f(y+K2 h/2)
+                for (int j = 0; j < RMT_NPT; ++j)
 #pragma unroll
-        for (int j = 0; j < RMT_NPT; ++j)
-#pragma unroll
-            for (int i = 0; i < RMT_V; ++i) { ACC(j, i) += real(2) * k[j][i]; ys[j][i] = Y0(j, i) + k[j][i] * h; }
-        rmt_rhs_block<RMT_NPT, false>(m, sh, 1, ys, nvalid, carry, k, flag);          // K4 = f(y+K3 h)
-#pragma unroll
-        for (int j = 0; j < RMT_NPT; ++j)
-#pragma unroll
-            for (int i = 0; i < RMT_V; ++i) {                                         // y + h(K1+2K2+2K3+K4)/6
-                const real yn = Y0(j, i) + h6 * (ACC(j, i) + k[j][i]);
-                Y0(j, i) = yn;
-                ys[j][i] = yn;
+                    for (int i = 0; i < RMT_V; ++i) {             // y + h(K1+2K2+2K3+K4)/6
+                        const real yn = Y0(j, i) + h6 * (ACC(j, i) + k[j][i]);
+                        Y0(j, i) = yn;
+                        ys[j][i] = yn;
+                    }
             }
+        }
     }
 #pragma unroll
     for (int j = 0; j < RMT_NPT; ++j) {
         if (j < nvalid) {
 #pragma unroll
             for (int i = 0; i < RMT_V; ++i) ye[(size_t)i * N + node0 + j] = ys[j][i];
-            flag |= rmt_finite_flag(ys[j]);
+            lflag |= rmt_finite_flag(ys[j]);
         }
     }
-    if (flag) atomicOr(&flags[e], flag);
+    lflag |= rmt_flags_bits(flag);
+    if (lflag) atomicOr(&flags[e], lflag);
 #undef Y0
 #undef ACC
 }
@@ -528,15 +579,23 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_mem(
         unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
     const int e = blockIdx.x;
+#if RMT_MEMBER_LDS
+    __shared__ RmtMember m;      // read back with broadcast ds_reads: frees ~2*(15+S) SGPRs
+    if (threadIdx.x == 0) rmt_load_member(members + (size_t)e * RMT_NM, m);
+    __syncthreads();
+#else
     RmtMember m;
     rmt_load_member(members + (size_t)e * RMT_NM, m);
+#endif
     const size_t per = (size_t)RMT_V * N, tot = per * E;
     real* ye = y + e * per;
     real* wa = work + e * per;
     real* wb = work + tot + e * per;
     real* wacc = work + 2 * tot + e * per;
     const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
-    unsigned flag = 0u;
+    rmt_flags_t flag;
+    rmt_flags_clear(flag);
+    unsigned lflag = 0u;
     int ph = 0;
     for (long long step = 0; step < nsteps; ++step) {
 #pragma unroll 1
@@ -568,14 +627,160 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_mem(
                         } else {
                             const real yn = ye[o] + h6 * a;
                             ye[o] = yn;
-                            flag |= __builtin_isfinite(yn) ? 0u : RMT_FLAG_NONFINITE;
+                            lflag |= __builtin_isfinite(yn) ? 0u : RMT_FLAG_NONFINITE;
                         }
                     }
                 }
             }
         }
     }
-    if (flag) atomicOr(&flags[e], flag);
+    lflag |= rmt_flags_bits(flag);
+    if (lflag) atomicOr(&flags[e], lflag);
+}
+
+// ===================================================================== kernel: adaptive RK45, state in memory
+// Dormand-Prince 5(4) (the pair behind SciPy's "RK45", which the reference reaches through
+// solve_ivp(method=...) at pbHomoReactor.py:3609) with PER-REACTOR step control: every workgroup
+// carries its own t, h and accept/reject history.  Controller (restated in oracle/n2_oracle.py
+// rk45, which the parity tests compare against):
+//   err = max_i |e_i| / (atol + rtol*max(|y_i|, |ynew_i|));  accept iff err <= 1
+//   h_new = h * clip(0.9*err^-0.2, 0.2, 5)  (no growth after a rejection);  a stage that produces a
+//   non-finite value (Python would raise inside a lambda: SURVEY.md Appendix C) rejects with h/4.
+// work = 8 arrays [E][V][N]: K1..K7 and the trial state.  FSAL: K7 of an accepted step is K1 of
+// the next.  Each thread only touches its own nodes' entries.
+__device__ static const double RMT_DP_A[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {1.0 / 5, 0, 0, 0, 0, 0},
+    {3.0 / 40, 9.0 / 40, 0, 0, 0, 0},
+    {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0, 0},
+    {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0, 0},
+    {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656, 0},
+    {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84}};
+__device__ static const double RMT_DP_E[7] = {      // b5 - b4
+    35.0 / 384 - 5179.0 / 57600, 0, 500.0 / 1113 - 7571.0 / 16695, 125.0 / 192 - 393.0 / 640,
+    -2187.0 / 6784 + 92097.0 / 339200, 11.0 / 84 - 187.0 / 2100, -1.0 / 40};
+
+__device__ __forceinline__ double rmt_block_max(RmtShared& sh, const int buf, double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+    if ((threadIdx.x & 63) == 0) sh.red[buf][threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = sh.red[buf][0];
+    for (int w = 1; w < RMT_NW; ++w) r = fmax(r, sh.red[buf][w]);
+    return r;
+}
+
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk45_mem(
+        real* __restrict__ y, real* __restrict__ work, const double* __restrict__ members,
+        const int N, const int E, const double t0, const double t1, const double rtol,
+        const double atol, const double h0, const long long max_steps,
+        double* __restrict__ stats /* [E][4]: t_end, h_last, accepted(i64), rejected(i64) */,
+        unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+    const int e = blockIdx.x;
+    RmtMember m;
+    rmt_load_member(members + (size_t)e * RMT_NM, m);
+    const size_t per = (size_t)RMT_V * N, tot = per * E;
+    real* ye = y + e * per;
+    real* wk = work + e * per;                  // K_{j+1}[o] = wk[j*tot + o]
+    real* yn = work + 7 * tot + e * per;
+    rmt_flags_t flag, trial;
+    rmt_flags_clear(flag);
+    unsigned lflag = 0u;
+    int ph = 0, rp = 0;
+    double t = t0, h = h0;
+    long long nacc = 0, nrej = 0;
+    bool have_k1 = false;
+    while (t < t1 && nacc + nrej < max_steps) {
+        bool last = false;
+        if (t + h >= t1) { h = t1 - t; last = true; }
+        rmt_flags_clear(trial);
+        double errloc = 0.0;
+        bool bad = false;
+#pragma unroll 1
+        for (int s = have_k1 ? 1 : 0; s < 7; ++s) {
+            // stage input: y + h*sum_j a[s][j] K_j ; s == 6 is the 5th-order solution itself
+            RmtCarry carry;
+            rmt_carry_inlet(m, carry);
+            for (int base = 0; base < N; base += RMT_BLOCK, ph ^= 1) {
+                const int node = base + (int)threadIdx.x;
+                const bool valid = node < N;
+                real ys[1][RMT_V], k[1][RMT_V];
+                rmt_safe_state(m, ys[0]);
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V; ++i) {
+                        const size_t o = (size_t)i * N + node;
+                        double acc = 0.0;
+                        for (int j = 0; j < s; ++j) acc += RMT_DP_A[s][j] * (double)wk[(size_t)j * tot + o];
+                        const double v = (double)ye[o] + h * acc;
+                        ys[0][i] = real(v);
+                        if (s == 6) yn[o] = real(v);
+                    }
+                }
+                rmt_rhs_block<1, true>(m, sh, ph, ys, valid ? 1 : 0, carry, k, trial);
+                if (valid) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V; ++i) {
+                        const size_t o = (size_t)i * N + node;
+                        wk[(size_t)s * tot + o] = k[0][i];
+                        bad |= !__builtin_isfinite(k[0][i]);
+                        if (s == 6) {
+                            double ev = 0.0;
+                            for (int j = 0; j < 7; ++j) ev += RMT_DP_E[j] * (double)wk[(size_t)j * tot + o];
+                            const double sc = atol + rtol * fmax(fabs((double)ye[o]), fabs((double)ys[0][i]));
+                            errloc = fmax(errloc, fabs(h * ev) / sc);
+                        }
+                    }
+                }
+            }
+            // a non-finite stage derivative: give up on this step early (wave-uniform decision)
+            const double anybad = rmt_block_max(sh, rp, bad ? 1.0 : 0.0);
+            rp ^= 1;
+            if (anybad > 0.0) { bad = true; break; }
+            have_k1 = true;     // K1 = f(y) is in place once stage 0 has run
+        }
+        double err = 0.0;
+        if (!bad) {
+            err = rmt_block_max(sh, rp, __builtin_isfinite(errloc) ? errloc : 1.0e300);
+            rp ^= 1;
+        }
+        double fac;
+        if (bad) {
+            fac = 0.25;
+            ++nrej;
+        } else if (err <= 1.0) {
+            t = last ? t1 : t + h;
+            ++nacc;
+            fac = (err == 0.0) ? 5.0 : fmin(5.0, fmax(0.2, 0.9 * pow(err, -0.2)));
+            // accept: y <- ynew, K1 <- K7 (FSAL)
+            for (int base = 0; base < N; base += RMT_BLOCK) {
+                const int node = base + (int)threadIdx.x;
+                if (node < N) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V; ++i) {
+                        const size_t o = (size_t)i * N + node;
+                        ye[o] = yn[o];
+                        wk[o] = wk[6 * tot + o];
+                    }
+                }
+            }
+            rmt_flags_merge(flag, trial, ~0ull);
+        } else {
+            ++nrej;
+            fac = fmax(0.2, 0.9 * pow(err, -0.2));     // K1 = f(y) stays valid after a rejection
+        }
+        h = fmax(h * fac, 1e-14);
+    }
+    if (t < t1) lflag |= RMT_FLAG_STEP;
+    lflag |= rmt_flags_bits(flag);
+    if (threadIdx.x == 0) {
+        stats[(size_t)e * 4 + 0] = t;
+        stats[(size_t)e * 4 + 1] = h;
+        ((long long*)stats)[(size_t)e * 4 + 2] = nacc;
+        ((long long*)stats)[(size_t)e * 4 + 3] = nrej;
+    }
+    if (lflag) atomicOr(&flags[e], lflag);
 }
 #endif  // RMT_HOST_EMULATION
 )RMTSRC"

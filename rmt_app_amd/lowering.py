@@ -496,19 +496,19 @@ class Lowered:
             elif op == "mul":
                 e = "%s * %s" % (A, B)
             elif op == "div":
-                pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (B, FLAG_DIV0))
+                pre.append("RMT_CHECK(flag, %s == real(0), %du);" % (B, FLAG_DIV0))
                 e = "rmt_div(%s, %s)" % (A, B)
             elif op == "rcp":
-                pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (A, FLAG_DIV0))
+                pre.append("RMT_CHECK(flag, %s == real(0), %du);" % (A, FLAG_DIV0))
                 e = "rmt_rcp(%s)" % A
             elif op == "expn":      # stands for 1/exp(A): Python raises if exp(A) overflows or is 0
-                pre.append("flag |= (%s > real(%r)) ? %du : 0u;" % (A, _EXP_MAX, FLAG_OVERFLOW))
-                pre.append("flag |= (%s < real(%r)) ? %du : 0u;" % (A, -745.1332191019411, FLAG_DIV0))
+                pre.append("RMT_CHECK(flag, %s > real(%r), %du);" % (A, _EXP_MAX, FLAG_OVERFLOW))
+                pre.append("RMT_CHECK(flag, %s < real(%r), %du);" % (A, -745.1332191019411, FLAG_DIV0))
                 e = "rmt_exp(-%s)" % A
             elif op in ("exp10n", "exp2n"):
                 lim = {"exp10n": 308.2547155599167, "exp2n": 1024.0}[op]
-                pre.append("flag |= (%s > real(%r)) ? %du : 0u;" % (A, lim, FLAG_OVERFLOW))
-                pre.append("flag |= (%s < real(%r)) ? %du : 0u;" % (A, -lim - 15.0, FLAG_DIV0))
+                pre.append("RMT_CHECK(flag, %s > real(%r), %du);" % (A, lim, FLAG_OVERFLOW))
+                pre.append("RMT_CHECK(flag, %s < real(%r), %du);" % (A, -lim - 15.0, FLAG_DIV0))
                 e = "rmt_%s(-%s)" % (op[:-1], A)
             elif op == "neg":
                 e = "-%s" % A
@@ -531,26 +531,27 @@ class Lowered:
                         sqname = nm
                 prod = " * ".join(terms)
                 if b < 0:
-                    pre.append("flag |= (%s == real(0)) ? %du : 0u;" % (A, FLAG_DIV0))
+                    pre.append("RMT_CHECK(flag, %s == real(0), %du);" % (A, FLAG_DIV0))
                     e = "real(1) / (%s)" % prod
                 else:
                     e = prod
             elif op == "pow":
-                pre.append("flag |= rmt_pow_flags(%s, %s);" % (A, B))
+                pre.append("RMT_CHECK(flag, %s < real(0) && %s != trunc(%s), %du);" % (A, B, B, FLAG_DOMAIN))
+                pre.append("RMT_CHECK(flag, %s == real(0) && %s < real(0), %du);" % (A, B, FLAG_DIV0))
                 e = "rmt_pow(%s, %s)" % (A, B)
             elif op in ("log", "log10", "log2", "log1p"):
                 bad = "<= real(0)" if op != "log1p" else "<= real(-1)"
-                pre.append("flag |= (%s %s) ? %du : 0u;" % (A, bad, FLAG_DOMAIN))
+                pre.append("RMT_CHECK(flag, %s %s, %du);" % (A, bad, FLAG_DOMAIN))
                 e = "rmt_%s(%s)" % (op, A)
             elif op == "sqrt":
-                pre.append("flag |= (%s < real(0)) ? %du : 0u;" % (A, FLAG_DOMAIN))
+                pre.append("RMT_CHECK(flag, %s < real(0), %du);" % (A, FLAG_DOMAIN))
                 e = "rmt_sqrt(%s)" % A
             elif op in ("exp", "exp10", "exp2", "expm1", "sinh", "cosh"):
                 lim = {"exp": _EXP_MAX, "expm1": _EXP_MAX, "sinh": 710.4758600739439,
                        "cosh": 710.4758600739439, "exp10": 308.2547155599167, "exp2": 1024.0}[op]
                 cond = ("%s > real(%r)" % (A, lim)) if op not in ("sinh", "cosh") else (
                     "rmt_abs(%s) > real(%r)" % (A, lim))
-                pre.append("flag |= (%s) ? %du : 0u;" % (cond, FLAG_OVERFLOW))
+                pre.append("RMT_CHECK(flag, %s, %du);" % (cond, FLAG_OVERFLOW))
                 e = "rmt_%s(%s)" % (op, A)
             elif op in ("sin", "cos", "tan", "tanh", "atan"):
                 e = "rmt_%s(%s)" % (op, A)
@@ -559,7 +560,7 @@ class Lowered:
             else:
                 raise LoweringError("no device emission for op %r" % op)
             for p in pre:
-                if p.startswith("flag |=") :
+                if p.startswith("RMT_CHECK("):
                     if p in seen_checks:
                         continue
                     seen_checks.add(p)
@@ -570,7 +571,7 @@ class Lowered:
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
         return (
             "__device__ __forceinline__ void %s(const real T, const real P, const real* __restrict__ x,\n"
-            "        const real* __restrict__ C, real* __restrict__ r, unsigned& flag) {\n%s\n%s\n}\n"
+            "        const real* __restrict__ C, real* __restrict__ r, rmt_flags_t& flag) {\n%s\n%s\n}\n"
             % (fname, body, outs))
 
 

@@ -41,7 +41,7 @@ class N2Device:
     """One compiled mechanism + E packed member rows on one GPU."""
 
     def __init__(self, mech, members, N, fp32=False, block=None, npt=None, device=None,
-                 extra_opts="", lds_state=None):
+                 extra_opts="", lds_state=None, defines=None):
         torch = _torch()
         self.torch = torch
         self.mech, self.N, self.fp32 = mech, int(N), bool(fp32)
@@ -56,8 +56,9 @@ class N2Device:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         tpl = hipbind.kernel_template()
         self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
-        src = mech.source(tpl, self.fp32, self.block, self.npt, self.lds_state)
-        key = mech.digest(tpl, self.fp32, self.block, self.npt, self.lds_state)
+        self.defines = dict(defines or {})
+        src = mech.source(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
+        key = mech.digest(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         code = hipbind.compile_cached(src, key, arch, extra_opts)
         self._code = C.create_string_buffer(code, len(code))

@@ -131,7 +131,7 @@ class Mechanism:
         return (hp - hr)*1000.00
 
     # ------------------------------------------------------------------ kernel source
-    def prelude(self, fp32=False, block=1024, npt=1, lds_state=None):
+    def prelude(self, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         def arr(vals):
             return "{" + ", ".join("real(%r)" % float(v) for v in vals) + "}"
         S, R = self.S, self.R
@@ -144,6 +144,7 @@ class Mechanism:
             "#define RMT_BLOCK %d" % block,
             "#define RMT_NPT %d" % npt,
             "#define RMT_LDS_STATE %d" % self.lds_state(fp32, block, npt, lds_state),
+        ] + ["#define %s %s" % (k, v) for k, v in sorted((defines or {}).items())] + [
             "typedef %s real;" % ("float" if fp32 else "double"),
             "__device__ static const real RMT_MW[RMT_S] = %s;" % arr(self.MW),
             "__device__ static const real RMT_DH25[RMT_R] = %s;" % arr(self.StHeRe25),
@@ -199,16 +200,16 @@ class Mechanism:
         fit = min(2, (144*1024)//per)
         return fit if want is None else min(int(want), fit)
 
-    def source(self, template, fp32=False, block=1024, npt=1, lds_state=None):
+    def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
         if "RMT_KINETICS_SOURCE" not in template:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
         body = template.replace("RMT_KINETICS_SOURCE", self.device_dag().emit("rmt_kinetics"), 1)
-        return self.prelude(fp32, block, npt, lds_state) + body
+        return self.prelude(fp32, block, npt, lds_state, defines) + body
 
-    def digest(self, template, fp32, block, npt, lds_state=None):
+    def digest(self, template, fp32, block, npt, lds_state=None, defines=None):
         h = hashlib.sha256()
-        h.update(self.source(template, fp32, block, npt, lds_state).encode())
+        h.update(self.source(template, fp32, block, npt, lds_state, defines).encode())
         return h.hexdigest()[:24]
 
 

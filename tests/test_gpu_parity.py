@@ -216,3 +216,64 @@ def test_rhs_near_steady_states_backward_stable():
         ok, d = backward_ok(out[k], F[k], fv, Y[k], 7)
         assert ok, (k, d)
     dev.close()
+
+
+@pytest.mark.parametrize("name,zNo,t1,rtol", [("dme_nb", 20, 4e-3, 1e-6), ("dme_nb", 100, 2e-3, 1e-5),
+                                              ("syn12", 20, 2e-2, 1e-6), ("ch4", 20, 1.0, 1e-7)])
+def test_rk45_vs_oracle_controller(name, zNo, t1, rtol):
+    """Adaptive Dormand-Prince with per-reactor step control against the oracle's restatement of
+    the same controller: same accept/reject history (within 2%), end state within 50*rtol."""
+    mi, mech, nm, dev = make_device(name, zNo)
+    y = dev.to_device(plan.initial_state(nm, mech, zNo))
+    atol, h0 = 1e-3*rtol, 1e-6
+    dev.rk45(y, 0.0, t1, rtol, atol, h0, 10**7)
+    assert not dev.status().any()
+    st = dev.rk45_stats()
+    pr = O.setup_n2(mi, zNo)
+    want, ost = O.rk45(O.make_rhs_vec(pr), 0.0, t1, pr["IV"], rtol, atol, h0)
+    assert st["t_end"][0] == t1
+    assert abs(int(st["accepted"][0]) - ost["accepted"]) <= max(2, 0.02*ost["accepted"])
+    assert abs(int(st["rejected"][0]) - ost["rejected"]) <= max(3, 0.05*ost["accepted"])
+    got = y.cpu().numpy()[0]
+    V = mech.V
+    scale = np.max(np.abs(want.reshape(V, zNo)), axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    assert np.max(np.abs(got.reshape(V, zNo) - want.reshape(V, zNo))/scale) < 50*rtol
+    dev.close()
+
+
+def test_rk45_per_reactor_step_control():
+    """Members with different inlet temperatures take different numbers of steps in one launch."""
+    N = 64
+    mech = plan.Mechanism(INP.dme_notebook_input())
+    rows, named = [], []
+    for T in (503, 523, 563):
+        m2 = INP.dme_notebook_input()
+        m2["operating-conditions"]["temperature"] = T
+        nm, row = plan.member_constants(m2, mech, N)
+        rows.append(row), named.append(nm)
+    dev = N2Device(mech, np.array(rows), N)
+    y = dev.to_device(np.array([plan.initial_state(nm, mech, N) for nm in named]))
+    dev.rk45(y, 0.0, 5e-3, 1e-6, 1e-9, 1e-6, 10**7)
+    assert not dev.status().any()
+    st = dev.rk45_stats()
+    assert np.all(st["t_end"] == 5e-3)
+    assert st["accepted"][0] < st["accepted"][1] < st["accepted"][2]      # hotter = stiffer
+    dev.close()
+
+
+def test_rmtexe_default_ivp_is_device_rk45_and_meets_1e6():
+    """An unmodified modelInput (ivp='default') runs on the device (adaptive RK45) and meets the
+    <= 1e-6 outlet requirement against the reference's tight LSODA run (golden G4)."""
+    g = np.load(os.path.join(G, "g4_tight_dme_nb_lsoda.npz"))
+    mi = INP.dme_notebook_input()          # ivp == "default"
+    mi["solver-config"].update({"quiet": True, "rtol": 1e-8, "atol": 1e-11})
+    res = rmtExe(mi)
+    dp = res["resModel"]["dataPack"]
+    worst = 0.0
+    for k in range(5):
+        a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
+        worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
+    assert worst < 1e-6, worst
+    st = res["resModel"]["device-stats"]
+    assert st["steps"] > 1000 and st["rejected"] is not None

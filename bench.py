@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_OPS_PER_NODE_STEP = 2106   # v_*_f64 instructions per node per RK4 step in rmt_n2_rk4_reg (DME, block 512 x 2)
 N_NODES = 1024
 MEMBERS_PER_GPU = 256
 DT = 2e-6
@@ -50,14 +51,27 @@ def sweep_member_inputs(first, count, total=2048):
     return out
 
 
+def host_cores():
+    """CPUs this job may actually use: cgroup quota if set (the GPU box gives 16 of its 256 logical
+    CPUs to a 1-GPU job), else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota)/int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(mech, rows, IV, N_NODES, seconds=12.0):
     """The oracle side, timed on this box's host cores: host emulation of the same generated
     source (oracle/hostemu_driver.cpp, OpenMP over members) running the identical RK4."""
     from oracle.hostemu import HostEmu
     from rmt_app_amd import hipbind
     emu = HostEmu(mech.source(hipbind.kernel_template()), tag="bench")
-    cores = os.cpu_count() or 1
-    E = min(len(rows), max(cores, 8))
+    cores = emu.set_threads(host_cores())
+    E = min(len(rows), max(2*cores, 8))
     y = IV[:E].copy()
     emu.rk4(y, rows[:E], N_NODES, DT, 2)          # warm-up
     steps, t_used = 0, 0.0
@@ -102,22 +116,24 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from rmt_app_amd import plan
-    from rmt_app_amd.n2 import N2Device
+    from rmt_app_amd.ensemble import DistributedEnsemble
+    from rmt_app_amd.n2 import N2Device, compile_mechanism
     n_nodes = args.nodes
     E = args.members
-    inputs = sweep_member_inputs(rank*E, E, total=max(2048, world*E))
+    total = world*E
+    # every rank describes the whole sweep cheaply (dict literals); DistributedEnsemble packs only
+    # the rank's own contiguous block of members and receives rank 0's code object over RCCL
+    inputs = sweep_member_inputs(0, total, total=max(2048, total))
     mech = plan.Mechanism(inputs[0])
-    pairs = [plan.member_constants(mi, mech, n_nodes) for mi in inputs]
-    rows = np.array([r for _, r in pairs])
-    if distributed:
-        # rank 0 owns the packed mechanism constants; broadcast over RCCL so every rank integrates
-        # with bit-identical tables (member rows stay rank-local: the sweep is index-derived).
-        tab = torch.tensor(np.concatenate([mech.nu.ravel(), mech.cp_coeff.ravel(), mech.StHeRe25]),
-                           device="cuda")
-        dist.broadcast(tab, src=0)
-    IV = np.array([plan.initial_state(nm, mech, n_nodes) for nm, _ in pairs])
+    defines = dict(d.split('=', 1) for d in args.define)
+    ens = DistributedEnsemble(
+        mech, inputs, n_nodes, device=torch.device("cuda", local),
+        compile_fn=lambda: compile_mechanism(mech, n_nodes, block=args.block, npt=args.npt,
+                                             lds_state=args.lds, defines=defines))
+    rows, IV = ens.rows, ens.IV
+    assert rows.shape[0] == E
     dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds,
-                   defines=dict(d.split('=', 1) for d in args.define))
+                   defines=defines, code=ens.code)
     dev.set_mode(args.mode)
     y = dev.to_device(IV)
 
@@ -140,11 +156,9 @@ def main():
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
-    # outlet rows (mole fractions need concentrations only) gathered for the record
-    outlet = y.reshape(E, mech.V, n_nodes)[:, :, -1].contiguous()
-    if distributed:
-        gathered = [torch.empty_like(outlet) for _ in range(world)] if rank == 0 else None
-        dist.gather(outlet, gathered, dst=0)
+    outlet = ens.gather_outlet(y)          # [world*E][V] on rank 0: the sweep's result table
+    if rank == 0:
+        assert outlet.shape == (total, mech.V) and bool(torch.isfinite(outlet).all())
 
     if rank == 0:
         node_steps = world*E*n_nodes*args.steps
@@ -165,7 +179,15 @@ def main():
                            dev.block, dev.npt, dev.lds_state)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved/HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step},
+                         "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step,
+                         "note": "state stays on chip for all steps of a launch; the limiter is fp64 "
+                                 "VALU issue, see valu_fp64"},
+            # the real ceiling of this kernel: fp64 vector issue (78.6 TFLOP/s spec = 39.3e12 fp64
+            # lane-instructions/s); ops/node-step is the static count in the kernel's ISA
+            "valu_fp64": {"ops_per_node_step": FP64_OPS_PER_NODE_STEP,
+                          "achieved_Tops": E*n_nodes*args.steps*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/1e12,
+                          "peak_Tops": 39.3,
+                          "frac": E*n_nodes*args.steps*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/39.3e12},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)

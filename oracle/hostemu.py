@@ -18,17 +18,19 @@ class HostEmu:
         key = hashlib.sha256((source + open(os.path.join(_HERE, "hostemu_driver.cpp")).read()
                               ).encode()).hexdigest()[:16]
         gen = os.path.join(_BUILD, "%s_%s.inc" % (tag, key))
-        so = os.path.join(_BUILD, "lib%s_%s.so" % (tag, key))
+        so = os.path.join(_BUILD, "lib%s_%s%s.so" % (tag, key, "" if openmp else "_st"))
         if not os.path.exists(so):
-            with open(gen, "w") as f:
+            uniq = ".%d.tmp" % os.getpid()          # concurrent builders (multi-rank tests) never share a file
+            with open(gen + uniq, "w") as f:
                 f.write(source)
+            os.replace(gen + uniq, gen)
             cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                    "-DRMT_GENERATED_SOURCE=\"%s\"" % gen,
-                   os.path.join(_HERE, "hostemu_driver.cpp"), "-o", so + ".tmp"]
+                   os.path.join(_HERE, "hostemu_driver.cpp"), "-o", so + uniq]
             if openmp:
                 cmd.insert(1, "-fopenmp")
             subprocess.run(cmd, check=True, capture_output=True)
-            os.replace(so + ".tmp", so)
+            os.replace(so + uniq, so)
         self.lib = C.CDLL(so)
         S, R, V, fp32 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         self.lib.emu_sizes(C.byref(S), C.byref(R), C.byref(V), C.byref(fp32))
@@ -39,6 +41,12 @@ class HostEmu:
         self.lib.emu_rhs.restype = None
         self.lib.emu_rk4.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_longlong, vp]
         self.lib.emu_rk4.restype = None
+        self.lib.emu_set_threads.argtypes = [C.c_int]
+        self.lib.emu_set_threads.restype = C.c_int
+
+    def set_threads(self, n):
+        """OpenMP threads used by rhs/rk4 (returns the number in effect; 1 without OpenMP)."""
+        return self.lib.emu_set_threads(int(n))
 
     def rhs(self, y, members, N):
         y = np.ascontiguousarray(y, dtype=self.dtype).reshape(-1, self.V*N)

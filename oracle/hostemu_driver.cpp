@@ -39,6 +39,13 @@ static void emu_rhs_one(const RmtMember& m, const real* y, real* dydt, int N, un
     }
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+extern "C" int emu_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+extern "C" int emu_set_threads(int) { return 1; }
+#endif
+
 extern "C" int emu_sizes(int* S, int* R, int* V, int* fp32) {
     *S = RMT_S; *R = RMT_R; *V = RMT_V; *fp32 = RMT_FP32;
     return 0;

@@ -1,0 +1,129 @@
+"""Ensembles of independent reactors (parameter sweeps) and their sharding over the GPUs of a node.
+
+The reference has no notion of an ensemble: a sweep is a Python loop over ``rmtExe`` calls.  Here
+the members share one compiled mechanism and differ only in their packed constant rows, so the
+whole sweep is one launch per output interval (one workgroup per member).
+
+Across GPUs the path shards along the ensemble dimension only: contiguous
+blocks of members per rank, one process per GPU, NO collective on the data path.  The only
+communication (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
+CPU tests) is
+  * one broadcast from rank 0 of the compiled code object + mechanism digest, so that every rank
+    runs the bit-identical kernel without recompiling, and
+  * one gather of the per-member outlet rows / status words to rank 0 per output time.
+"""
+import copy
+
+import numpy as np
+
+
+def deep_merge(base, override):
+    """Member description = base modelInput with nested keys replaced."""
+    out = copy.copy(base)
+    for k, v in override.items():
+        if isinstance(v, dict) and isinstance(base.get(k), dict):
+            out[k] = deep_merge(base[k], v)
+        else:
+            out[k] = v
+    return out
+
+
+def expand_members(modelInput, spec):
+    """``solver-config.ensemble`` -> list of member modelInputs.
+
+    * a list of dicts: each is merged over ``modelInput`` (full modelInputs work too);
+    * a dict ``{"temperature": [...], "pressure": [...]}``: the cartesian sweep of SURVEY.md
+      section 8(d).4 - member = iT*len(P) + iP, feed concentrations recomputed as y0*P/(R*T) from
+      the base feed's mole fractions.
+    """
+    if isinstance(spec, dict):
+        from .plan import R_CONST
+        Ts = np.atleast_1d(np.asarray(spec.get("temperature", [modelInput['operating-conditions']['temperature']]), float))
+        Ps = np.atleast_1d(np.asarray(spec.get("pressure", [modelInput['operating-conditions']['pressure']]), float))
+        c0 = np.asarray(modelInput['feed']['concentration'], dtype=float)
+        y0 = c0/c0.sum()
+        out = []
+        for T in Ts:
+            for P in Ps:
+                out.append(deep_merge(modelInput, {
+                    "operating-conditions": {"temperature": float(T), "pressure": float(P)},
+                    "feed": {"concentration": y0*float(P)/(R_CONST*float(T))}}))
+        return out
+    return [deep_merge(modelInput, m) for m in spec]
+
+
+def shard(n_members, world, rank):
+    """Contiguous block [lo, hi) of members owned by ``rank`` (sizes differ by at most one)."""
+    base, extra = divmod(n_members, world)
+    lo = rank*base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def broadcast_bytes(blob, src=0, group=None, device=None):
+    """Broadcast a bytes object from ``src`` (length first, then payload) via torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=src, group=group)
+    buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    if rank == src:
+        buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    dist.broadcast(buf, src=src, group=group)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def gather_rows(local, counts, dst=0, group=None):
+    """Gather per-member rows (2-D tensors with differing first dimension) on ``dst``;
+    returns the concatenated tensor there and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    pad = max(counts)
+    padded = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]] = local
+    if rank == dst:
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.gather(padded, parts, dst=dst, group=group)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    dist.gather(padded, None, dst=dst, group=group)
+    return None
+
+
+class DistributedEnsemble:
+    """Rank-local slice of an ensemble + the two collectives described in the module docstring.
+
+    ``make_stepper(mech, rows, code)`` builds the rank-local integrator from the member rows and
+    the (broadcast) code object; on the GPU box that is ``N2Device``; the CPU tests inject a stand-in
+    to exercise partitioning and communication without a device.
+    """
+
+    def __init__(self, mech, member_inputs, zNo, group=None, device=None, compile_fn=None):
+        import torch.distributed as dist
+        from . import plan
+        self.mech, self.zNo, self.group, self.device = mech, zNo, group, device
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n_total = len(member_inputs)
+        self.lo, self.hi = shard(self.n_total, self.world, self.rank)
+        self.counts = [shard(self.n_total, self.world, r)[1] - shard(self.n_total, self.world, r)[0]
+                       for r in range(self.world)]
+        mine = member_inputs[self.lo:self.hi]
+        pairs = [plan.member_constants(mi, mech, zNo) for mi in mine]
+        self.named = [nm for nm, _ in pairs]
+        self.rows = np.array([r for _, r in pairs]).reshape(len(mine), plan.MEMBER_FIXED + mech.S)
+        self.IV = np.array([plan.initial_state(nm, mech, zNo) for nm in self.named]).reshape(
+            len(mine), mech.V*zNo)
+        # rank 0 compiles; everyone receives the identical code object
+        code = compile_fn() if (self.rank == 0 and compile_fn is not None) else b""
+        if self.world > 1:
+            code = broadcast_bytes(code, 0, group, device)
+        self.code = code
+
+    def gather_outlet(self, y_local):
+        """y_local: tensor [E_local][V*N] -> on rank 0 the outlet rows [E_total][V] (node N-1)."""
+        outlet = y_local.reshape(y_local.shape[0], self.mech.V, self.zNo)[:, :, -1].contiguous()
+        if self.world == 1:
+            return outlet
+        return gather_rows(outlet, self.counts, 0, self.group)

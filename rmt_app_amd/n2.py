@@ -41,7 +41,7 @@ class N2Device:
     """One compiled mechanism + E packed member rows on one GPU."""
 
     def __init__(self, mech, members, N, fp32=False, block=None, npt=None, device=None,
-                 extra_opts="", lds_state=None, defines=None):
+                 extra_opts="", lds_state=None, defines=None, code=None):
         torch = _torch()
         self.torch = torch
         self.mech, self.N, self.fp32 = mech, int(N), bool(fp32)
@@ -60,7 +60,8 @@ class N2Device:
         src = mech.source(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
         key = mech.digest(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
-        code = hipbind.compile_cached(src, key, arch, extra_opts)
+        if code is None:      # an ensemble rank may receive rank 0's code object instead
+            code = hipbind.compile_cached(src, key, arch, extra_opts)
         self._code = C.create_string_buffer(code, len(code))
         p = hipbind.Plan()
         p.abi_version = hipbind.ABI_VERSION
@@ -190,6 +191,17 @@ def _progress(i, total, quiet):
     filled = int(50*i//total)
     print('\rProgress: |%s| %s%% Complete' % ('█'*filled + '-'*(50 - filled), pct),
           end="\r" if i < total else "\n")
+
+
+def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None, defines=None,
+                      arch="gfx950"):
+    """Code object for (mechanism, mesh size) - what ensemble rank 0 compiles and broadcasts."""
+    b, n = choose_geometry(N, mech.V, fp32)
+    block, npt = int(block or b), int(npt or n)
+    ls = mech.lds_state(fp32, block, npt, lds_state)
+    tpl = hipbind.kernel_template()
+    return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, ls, defines),
+                                  mech.digest(tpl, fp32, block, npt, ls, defines), arch)
 
 
 def run_n2(modelInput, members_inputs=None):

@@ -27,6 +27,9 @@ def rmtExe(modelInput):
         if modelType == "N2":
             from .n2 import run_n2
             ensemble = modelInput['solver-config'].get('ensemble')
+            if ensemble is not None:
+                from .ensemble import expand_members
+                ensemble = expand_members(modelInput, ensemble)
             resModel = run_n2(modelInput, ensemble)
         else:
             raise NotImplementedError(

@@ -1,1 +1,9 @@
-for g in "512 2 2" "1024 1 2"; do for u in 0 1; do for ml in 0 1; do set -- $g; echo "== block $1 npt $2 lds $3 unroll $u memberlds $ml"; timeout -k 10 200 python bench.py --no-cpu-baseline --block $1 --npt $2 --lds $3 --define RMT_STAGE_UNROLL=$u --define RMT_MEMBER_LDS=$ml --steps 1000 --warmup 100 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"]/1e9, \"G node-steps/s\", d[\"ms_per_step\"])"; done; done; done
+# usage: bash tools/sweep.sh  -- quick A/B of kernel shapes on one GPU
+run() { echo "== $*"; timeout -k 10 300 python bench.py --no-cpu-baseline --steps 1000 --warmup 100 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('   %.3f G node-steps/s  %.4f ms/step  valu %.3f' % (d['value']/1e9, d['ms_per_step'], d['valu_fp64']['frac']))"; }
+run --members 256 --block 512 --npt 2 --lds 2
+run --members 512 --block 512 --npt 2 --lds 1
+run --members 512 --block 512 --npt 2 --lds 0
+run --members 512 --block 256 --npt 4 --lds 1
+run --members 1024 --block 256 --npt 4 --lds 0
+run --members 1024 --block 512 --npt 2 --lds 0
+run --members 2048 --block 512 --npt 2 --lds 2

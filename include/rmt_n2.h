@@ -18,6 +18,8 @@
  *                         from the `ivp == "AM"` plug point pbHomoReactor.py:3598-3607 (only the
  *                         last column - the end state - is produced, which is all runN2 keeps,
  *                         :3630, :3685).
+ *   rmt_n2_multistep    - AdBash3 / PreCorr3, PyREMOT/solvers/odeSolver.py:43-102; PreCorr3 is what
+ *                         runN2 calls for ivp == "AM" (pbHomoReactor.py:3598-3601).
  *   rmt_n2_rk45         - scipy.integrate.solve_ivp(funSet, t, IV, method=..., args=(paramsSet,))
  *                         at pbHomoReactor.py:3609-3610, restricted to an explicit embedded pair
  *                         (Dormand-Prince 5(4)) with per-reactor step control.
@@ -97,6 +99,8 @@ int rmt_n2_set_members(rmt_n2_handle* h, const double* members);
 
 int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt);
 int rmt_n2_rk4(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t nsteps);
+/* method: 0 = AdBash3, 1 = PreCorr3 (needs nsteps >= 3, like the reference) */
+int rmt_n2_multistep(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t nsteps, int method);
 int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 /* copies the E flag words to host memory (synchronises the stream) and clears them on device */

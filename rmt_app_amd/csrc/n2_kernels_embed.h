@@ -782,5 +782,137 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk45_mem(
     }
     if (lflag) atomicOr(&flags[e], lflag);
 }
+
+// ===================================================================== kernel: Adams multistep, state in memory
+// The reference's other two hand-written integrators (PyREMOT/solvers/odeSolver.py:43-102):
+// AdBash3 (method 0) and the AB3 predictor / AM4 corrector PreCorr3 (method 1) that runN2 selects
+// with ivp == "AM" (pbHomoReactor.py:3598-3601).  Same start-up as there: two RK4 steps give
+// y_1, y_2; K2 = f(y_0), K1 = f(y_1); then for i = 2..n-1
+//   K3,K2 <- K2,K1; K1 = f(y_i); y_{i+1} = y_i + h(23K1-16K2+5K3)/12            [AB3 / predictor]
+//   K0 = f(y_{i+1}); y_{i+1} = y_i + h(9K0+19K1-5K2+K3)/24                      [PreCorr3 only]
+// work = 8 arrays [E][V][N]: RK4 scratch (3), K ring (3), K0, predictor.
+__device__ __forceinline__ void rmt_eval_mem(const RmtMember& m, RmtShared& sh, int& ph,
+                                             const real* src, real* dst,   // may alias (in-place)
+                                             const int N, rmt_flags_t& flag) {
+    RmtCarry carry;
+    rmt_carry_inlet(m, carry);
+    for (int base = 0; base < N; base += RMT_BLOCK, ph ^= 1) {
+        const int node = base + (int)threadIdx.x;
+        const bool valid = node < N;
+        real ys[1][RMT_V], k[1][RMT_V];
+        rmt_safe_state(m, ys[0]);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) ys[0][i] = src[(size_t)i * N + node];
+        }
+        rmt_rhs_block<1, true>(m, sh, ph, ys, valid ? 1 : 0, carry, k, flag);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) dst[(size_t)i * N + node] = k[0][i];
+        }
+    }
+}
+
+__device__ __forceinline__ void rmt_rk4_step_mem(const RmtMember& m, RmtShared& sh, int& ph,
+                                                 real* __restrict__ ye, real* __restrict__ wa,
+                                                 real* __restrict__ wb, real* __restrict__ wacc,
+                                                 const int N, const real h, rmt_flags_t& flag) {
+    const real hh = real(0.5) * h, h6 = h / real(6);
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        const real* src = (s == 0) ? ye : ((s == 2) ? wb : wa);
+        real* dst = (s == 1) ? wb : wa;
+        rmt_eval_mem(m, sh, ph, src, (s == 0) ? wacc : dst, N, flag);   // K into wacc (s=0) or dst
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    if (s == 0) {
+                        wa[o] = ye[o] + wacc[o] * hh;                    // acc = K1 stays in wacc
+                    } else if (s == 1) {
+                        const real k = wb[o];
+                        wacc[o] += real(2) * k;
+                        wb[o] = ye[o] + k * hh;
+                    } else if (s == 2) {
+                        const real k = wa[o];
+                        wacc[o] += real(2) * k;
+                        wa[o] = ye[o] + k * h;
+                    } else {
+                        ye[o] += h6 * (wacc[o] + wa[o]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_multistep_mem(
+        real* __restrict__ y, real* __restrict__ work, const double* __restrict__ members,
+        const int N, const int E, const double h_, const long long nsteps, const int method,
+        unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+    const int e = blockIdx.x;
+    RmtMember m;
+    rmt_load_member(members + (size_t)e * RMT_NM, m);
+    const size_t per = (size_t)RMT_V * N, tot = per * E;
+    real* ye = y + e * per;
+    real* wa = work + e * per;
+    real* wb = work + tot + e * per;
+    real* wacc = work + 2 * tot + e * per;
+    real* k1 = work + 3 * tot + e * per;
+    real* k2 = work + 4 * tot + e * per;
+    real* k3 = work + 5 * tot + e * per;
+    real* k0 = work + 6 * tot + e * per;
+    real* yp = work + 7 * tot + e * per;
+    const real h = real(h_);
+    rmt_flags_t flag;
+    rmt_flags_clear(flag);
+    unsigned lflag = 0u;
+    int ph = 0;
+    rmt_eval_mem(m, sh, ph, ye, k2, N, flag);                    // K2 = f(y_0)
+    rmt_rk4_step_mem(m, sh, ph, ye, wa, wb, wacc, N, h, flag);   // y_1
+    rmt_eval_mem(m, sh, ph, ye, k1, N, flag);                    // K1 = f(y_1)
+    rmt_rk4_step_mem(m, sh, ph, ye, wa, wb, wacc, N, h, flag);   // y_2
+    for (long long i = 2; i < nsteps; ++i) {
+        real* t = k3; k3 = k2; k2 = k1; k1 = t;                  // K3 = K2; K2 = K1
+        rmt_eval_mem(m, sh, ph, ye, k1, N, flag);                // K1 = f(y_i)
+        real* dst = (method == 1) ? yp : ye;
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int v = 0; v < RMT_V; ++v) {
+                    const size_t o = (size_t)v * N + node;
+                    dst[o] = ye[o] + h * (real(23) * k1[o] - real(16) * k2[o] + real(5) * k3[o]) / real(12);
+                }
+            }
+        }
+        if (method == 1) {
+            rmt_eval_mem(m, sh, ph, yp, k0, N, flag);            // K0 = f(predictor)
+            for (int base = 0; base < N; base += RMT_BLOCK) {
+                const int node = base + (int)threadIdx.x;
+                if (node < N) {
+#pragma unroll
+                    for (int v = 0; v < RMT_V; ++v) {
+                        const size_t o = (size_t)v * N + node;
+                        ye[o] = ye[o] + h * (real(9) * k0[o] + real(19) * k1[o] - real(5) * k2[o] + k3[o]) / real(24);
+                    }
+                }
+            }
+        }
+    }
+    for (int base = 0; base < N; base += RMT_BLOCK) {
+        const int node = base + (int)threadIdx.x;
+        if (node < N) {
+#pragma unroll
+            for (int v = 0; v < RMT_V; ++v)
+                lflag |= __builtin_isfinite(ye[(size_t)v * N + node]) ? 0u : RMT_FLAG_NONFINITE;
+        }
+    }
+    lflag |= rmt_flags_bits(flag);
+    if (lflag) atomicOr(&flags[e], lflag);
+}
 #endif  // RMT_HOST_EMULATION
 )RMTSRC"

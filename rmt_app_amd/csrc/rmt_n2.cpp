@@ -40,7 +40,7 @@ struct rmt_n2_handle {
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
-                  f_rk45_mem = nullptr;
+                  f_rk45_mem = nullptr, f_multistep = nullptr;
     double* d_members = nullptr;
     unsigned* d_flags = nullptr;
     void* d_work = nullptr;
@@ -149,6 +149,8 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         h->f_rk45_reg = nullptr;
     if (hipModuleGetFunction(&h->f_rk45_mem, h->module, "rmt_n2_rk45_mem") != hipSuccess)
         h->f_rk45_mem = nullptr;
+    if (hipModuleGetFunction(&h->f_multistep, h->module, "rmt_n2_multistep_mem") != hipSuccess)
+        h->f_multistep = nullptr;
     (void)hipGetLastError();
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
     CREATE_OK(hipMalloc((void**)&h->d_members, mbytes));
@@ -254,6 +256,21 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
     void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,
                     (void*)&dt, (void*)&ns, (void*)&h->d_flags};
     return launch(h, h->f_rk4_mem, args);
+}
+
+extern "C" int rmt_n2_multistep(rmt_n2_handle* h, void* y, double t0, double dt, int64_t nsteps,
+                                int method) {
+    (void)t0;
+    if (!h || !y) return fail("null argument");
+    if (!(dt > 0) || nsteps < 3) return fail("multistep needs dt > 0 and nsteps >= 3");
+    if (method != 0 && method != 1) return fail("method must be 0 (AdBash3) or 1 (PreCorr3)");
+    if (!h->f_multistep) return fail("code object has no multistep kernel");
+    if (ensure_work(h, 8)) return 1;
+    int N = h->N, E = h->E;
+    long long ns = (long long)nsteps;
+    void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,
+                    (void*)&dt, (void*)&ns, (void*)&method, (void*)&h->d_flags};
+    return launch(h, h->f_multistep, args);
 }
 
 extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, double rtol, double atol,

@@ -15,7 +15,7 @@ from . import hipbind, plan
 from .lowering import FLAG_DIV0, FLAG_DOMAIN, FLAG_NONFINITE, FLAG_OVERFLOW, FLAG_STEP
 from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 
-DEVICE_IVPS = ("hip-rk4", "hip-rk45")
+DEVICE_IVPS = ("hip-rk4", "hip-rk45", "AM", "hip-ab3")
 
 
 def choose_geometry(N, V, fp32=False):
@@ -119,6 +119,13 @@ class N2Device:
         self._chk_state(y)
         hipbind.check(hipbind.lib().rmt_n2_rk4(self.h, C.c_void_p(y.data_ptr()), float(t0), float(dt),
                                                int(nsteps)))
+
+    def multistep(self, y, dt, nsteps, method="PreCorr3", t0=0.0):
+        """In place: the reference's AdBash3 / PreCorr3 (odeSolver.py:43-102), nsteps >= 3."""
+        self._chk_state(y)
+        hipbind.check(hipbind.lib().rmt_n2_multistep(
+            self.h, C.c_void_p(y.data_ptr()), float(t0), float(dt), int(nsteps),
+            {"AdBash3": 0, "PreCorr3": 1}[method]))
 
     def rk45(self, y, t0, t1, rtol, atol, h0, max_steps):
         self._chk_state(y)
@@ -244,6 +251,13 @@ def run_n2(modelInput, members_inputs=None):
                 dev.rk4(y, (t1 - t0)/n, n, t0)
                 stats["steps"] += n
                 stats["rhs_evals"] += 4*n
+            elif ivp in ("AM", "hip-ab3"):
+                # the reference's plug point: PreCorr3 with n fixed steps per output interval,
+                # n from solverSetting['T1']['ode-solver']['PreCorr3']['n'] (pbHomoReactor.py:3572,3601)
+                n = int(cfg.get('n', solverSetting['T1']['ode-solver']['PreCorr3']['n']))
+                dev.multistep(y, abs(t1 - t0)/n, n, "PreCorr3" if ivp == "AM" else "AdBash3", t0)
+                stats["steps"] += n
+                stats["rhs_evals"] += (2*n + 6) if ivp == "AM" else (n + 8)
             else:
                 dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
                          float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])),
@@ -260,7 +274,7 @@ def run_n2(modelInput, members_inputs=None):
         if stats["accepted"] is not None:
             stats["steps"] = int(np.sum(stats["accepted"]))
             stats["rhs_evals"] = int(np.sum(6*(stats["accepted"] + stats["rejected"])) + len(inputs)*tNo)
-        stats["node_steps"] = stats["steps"]*zNo*(len(inputs) if ivp == "hip-rk4" else 1)
+        stats["node_steps"] = stats["steps"]*zNo*(len(inputs) if ivp != "hip-rk45" else 1)
     finally:
         dev.close()
     elapsed = np.round(timer() - start, ROUND_FUN_ACCURACY)

@@ -277,3 +277,41 @@ def test_rmtexe_default_ivp_is_device_rk45_and_meets_1e6():
     assert worst < 1e-6, worst
     st = res["resModel"]["device-stats"]
     assert st["steps"] > 1000 and st["rejected"] is not None
+
+
+@pytest.mark.parametrize("name", ["dme_nb", "ch4"])
+@pytest.mark.parametrize("meth", ["PreCorr3", "AdBash3"])
+def test_multistep_vs_reference_trajectory(name, meth):
+    """The reference's `ivp == "AM"` integrators on the device vs its own Python versions (G3b)."""
+    g = np.load(os.path.join(G, "g3b_multistep.npz"))
+    h, n = float(g[name + "_20_h"]), int(g[name + "_20_n"])
+    want = g["%s_20_%s" % (name, meth)]
+    scale = np.maximum(np.max(np.abs(want), axis=1), 1e-300)
+    for col, steps in enumerate((3, n//2, n)):
+        _, mech, nm, dev = make_device(name, 20)
+        y = dev.to_device(plan.initial_state(nm, mech, 20))
+        dev.multistep(y, h, steps, meth)
+        assert not dev.status().any()
+        assert np.max(np.abs(y.cpu().numpy()[0] - want[:, col])/scale) < 1e-9, (steps,)
+        dev.close()
+
+
+def test_rmtexe_am_plug_point():
+    """ivp='AM' (PreCorr3, n=100 per interval, pbHomoReactor.py:3572,3598-3607): works for the mild
+    CH4 case and, like the reference's own Python path on the DME case, raises
+    when h = 1e-3 s is far above the stability limit."""
+    mi = INP.ch4_input(ivp="AM", period=2.0)
+    mi["solver-config"]["quiet"] = True
+    res = rmtExe(mi)
+    pr = O.setup_n2(INP.ch4_input(), 20)
+    f = O.make_rhs_vec(pr)
+    yv = pr["IV"]
+    for k in range(5):
+        yv = O.precorr3(0.4*k, 0.4*(k + 1), 100, yv, f)[:, -1]
+        got = res["resModel"]["dataPack"][k]
+        want = O.pack_interval(yv, pr, 0.4*(k + 1))
+        np.testing.assert_allclose(got["dataYs"], want["dataYs"], rtol=1e-10)
+    mi = INP.dme_script_input(ivp="AM")
+    mi["solver-config"]["quiet"] = True
+    with pytest.raises((OverflowError, FloatingPointError, ValueError, ZeroDivisionError)):
+        rmtExe(mi)

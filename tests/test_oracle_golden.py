@@ -152,3 +152,17 @@ def test_n1_profile_vs_reference():
     assert relerr(res["dataYs"], g["dataYs"]) < 1e-7
     out = res["dataYs"][:, -1]
     assert abs(out[7] - 620.85663988) < 1e-4 and abs(out[6] - 4992662.9644) < 1.0
+
+
+@pytest.mark.parametrize("name", ["dme_nb", "ch4"])
+def test_multistep_vs_reference(name):
+    """Oracle AdBash3 / PreCorr3 against the reference's own (odeSolver.py:43-102), golden G3b."""
+    g = np.load(os.path.join(G, "g3b_multistep.npz"))
+    h, n = float(g[name + "_20_h"]), int(g[name + "_20_n"])
+    pr = O.setup_n2(INP.ALL_N2_INPUTS[name](), 20)
+    f = O.make_rhs_vec(pr)
+    for meth, fn in (("PreCorr3", O.precorr3), ("AdBash3", O.adbash3)):
+        want = g["%s_20_%s" % (name, meth)]
+        got = fn(0.0, n*h, n, pr["IV"], f)[:, [3, n//2, n]]
+        scale = np.maximum(np.max(np.abs(want), axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(got - want)/scale) < 1e-11, meth

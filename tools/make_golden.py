@@ -251,6 +251,21 @@ def g_rk4():
 
 
 # --------------------------------------------------------------------------- G4/G5
+def g_multistep():
+    """Reference PreCorr3 / AdBash3 (PyREMOT/solvers/odeSolver.py:43-102) trajectories."""
+    out = {}
+    for name, zNo, h, n in [("dme_nb", 20, 2e-6, 120), ("ch4", 20, 1e-3, 120)]:
+        mi = INP.ALL_N2_INPUTS[name]()
+        IV, params = capture(mi, zNo)
+        for meth in ("PreCorr3", "AdBash3"):
+            traj = getattr(ODES, meth)(0.0, n*h, n, IV, PB.modelEquationN2, params)
+            out["%s_%d_%s" % (name, zNo, meth)] = traj[:, [3, n//2, n]]
+        out["%s_%d_h" % (name, zNo)] = np.array(h)
+        out["%s_%d_n" % (name, zNo)] = np.array(n)
+    np.savez_compressed(os.path.join(GOLD, "g3b_multistep.npz"), **out)
+    print("G3b written")
+
+
 def g_tight(which):
     name, method = which.split(":")
     tol = {"lsoda": ("LSODA", 1e-10, 1e-12), "bdf": ("BDF", 1e-9, 1e-12)}[method]
@@ -364,6 +379,8 @@ def main(argv):
             g_tight(what.split("=", 1)[1])
         elif what.startswith("default="):
             g_default(what.split("=", 1)[1])
+        elif what == "multistep":
+            g_multistep()
         elif what == "n1":
             g_n1()
         elif what == "helpers":

@@ -110,7 +110,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
-    distributed = world > 1
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun, even alone
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))

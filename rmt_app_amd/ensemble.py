@@ -117,13 +117,14 @@ class DistributedEnsemble:
             len(mine), mech.V*zNo)
         # rank 0 compiles; everyone receives the identical code object
         code = compile_fn() if (self.rank == 0 and compile_fn is not None) else b""
-        if self.world > 1:
+        if dist.is_initialized():
             code = broadcast_bytes(code, 0, group, device)
         self.code = code
 
     def gather_outlet(self, y_local):
         """y_local: tensor [E_local][V*N] -> on rank 0 the outlet rows [E_total][V] (node N-1)."""
         outlet = y_local.reshape(y_local.shape[0], self.mech.V, self.zNo)[:, :, -1].contiguous()
-        if self.world == 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
             return outlet
         return gather_rows(outlet, self.counts, 0, self.group)

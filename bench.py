@@ -129,7 +129,7 @@ def main():
     ens = DistributedEnsemble(
         mech, inputs, n_nodes, device=torch.device("cuda", local),
         compile_fn=lambda: compile_mechanism(mech, n_nodes, block=args.block, npt=args.npt,
-                                             lds_state=args.lds, defines=defines))
+                                             lds_state=args.lds, defines=defines, E=E))
     rows, IV = ens.rows, ens.IV
     assert rows.shape[0] == E
     dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds,

@@ -105,7 +105,8 @@ int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rt
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 /* copies the E flag words to host memory (synchronises the stream) and clears them on device */
 int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
-/* which stepper rmt_n2_rk4 uses: 0 = auto, 1 = register-resident, 2 = memory-resident */
+/* which stepper rmt_n2_rk4 uses: 0 = auto (on-chip if N fits one workgroup, else chained
+ * workgroups, else memory), 1 = on-chip single workgroup, 2 = memory-resident, 3 = chained */
 int rmt_n2_set_mode(rmt_n2_handle* h, int mode);
 /* timing of the last rk4/rk45/rhs launch in ms (HIP events on the handle's stream; synchronises) */
 int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms);

@@ -298,7 +298,49 @@ struct RmtShared {
     preal tot_b[2][RMT_NW];
     real bnd[2][RMT_NW][RMT_V];
     real red[2][RMT_NW];
+    double cin[2][RMT_V + 1];     // chained workgroups: upstream record (up[V], P) of this stage
+    int abort[2];
 };
+
+// ---- chained workgroups (one reactor spread over C workgroups) --------------------------------
+// Information only flows downstream (upwind stencil, pressure march from the inlet), so the
+// workgroups of a reactor form a producer->consumer chain with NO grid barrier: per RHS stage,
+// chunk c hands chunk c+1 one record {clamped state of its last node, pressure after its last
+// node} through a ring of RMT_CHAIN_DEPTH slots in global memory.  Protocol = the fence-free
+// form of the CDNA guide (MI355X_MICROARCH "Valid forms", table row 1): every payload byte is
+// stored sc1 (agent-scope relaxed atomic store = write-through) by ONE wave, that wave drains
+// vmcnt, then ONE lane stores the sequence flag sc1; the consumer's polling wave reads the flag
+// and then the payload with sc1 loads (agent-scope relaxed atomic loads, L1-bypassing).  A
+// consumed-counter gives back-pressure.  (The release/acquire-fence form measured ~3 us more per
+// stage.)  Every spin is bounded; a timeout poisons both counters so that the whole
+// chain drains and the launch ends with RMT_FLAG_STEP instead of hanging.
+#ifndef RMT_CHAIN_DEPTH
+#define RMT_CHAIN_DEPTH 8
+#endif
+#define RMT_CHAIN_POISON (~0ull)
+#define RMT_CHAIN_SPINS (1u << 22)
+#define RMT_SYNC_STRIDE 32        // u64 words per link: [0] published seq, [16] consumed seq (own 128-B lines)
+
+struct RmtChainCtx {
+    bool has_in, has_out;
+    unsigned long long* sync_in;      // link c-1 -> c
+    unsigned long long* sync_out;     // link c -> c+1
+    const double* slots_in;
+    double* slots_out;
+    unsigned long long q;             // sequence number of the current stage (1, 2, ...)
+    int abort;                        // workgroup-uniform, valid after the stage's barrier
+};
+
+__device__ __forceinline__ int rmt_chain_wait(unsigned long long* word, const unsigned long long need) {
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == RMT_CHAIN_POISON) return 1;
+        if (v >= need) return 0;
+        if (++spins > RMT_CHAIN_SPINS) return 1;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 
 struct RmtCarry {       // workgroup-uniform hand-over between consecutive node blocks
     preal P;            // pressure at the first node of the block
@@ -317,11 +359,11 @@ __device__ __forceinline__ void rmt_carry_inlet(const RmtMember& m, RmtCarry& c)
 // RHS for the NPT consecutive nodes owned by this thread (nodes base+tid*NPT ...).
 // `nvalid` = how many of them exist (< NPT only at the reactor's end).  One __syncthreads().
 // buf = LDS ping-pong index; callers alternate it between consecutive calls.
-template <int NPT, bool CARRY_OUT>
+template <int NPT, bool CARRY_OUT, bool CHAIN = false>
 __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh, const int buf,
                                               const real (&ys)[NPT][RMT_V], const int nvalid,
                                               RmtCarry& carry, real (&k)[NPT][RMT_V],
-                                              rmt_flags_t& flag) {
+                                              rmt_flags_t& flag, RmtChainCtx* ctx = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     RmtNode nd[NPT];
@@ -363,7 +405,37 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
     real up[RMT_V];
 #pragma unroll
     for (int i = 0; i < RMT_V; ++i) up[i] = __shfl_up(last[i], 1);
+    if (CHAIN) {
+        if (wave == 0) {                          // all waiting is done by one wave, before the barrier
+            int st = 0;
+            double rec = 0.0;
+            if (ctx->has_in) {
+                if (lane == 0) st = rmt_chain_wait(ctx->sync_in, ctx->q);
+                st = __shfl(st, 0);
+                if (lane <= RMT_V) {              // sc1 load (bypasses this CU's L1): no acquire fence needed
+                    rec = __longlong_as_double((long long)__hip_atomic_load(
+                        (const unsigned long long*)ctx->slots_in +
+                            (size_t)(ctx->q % RMT_CHAIN_DEPTH) * (RMT_V + 1) + lane,
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    sh.cin[buf][lane] = rec;
+                }
+            }
+            if (ctx->has_out && lane == 0 && ctx->q > RMT_CHAIN_DEPTH)      // slot free again?
+                st |= rmt_chain_wait(ctx->sync_out + 16, ctx->q - RMT_CHAIN_DEPTH);
+            if (lane == 0) sh.abort[buf] = st;
+        }
+    }
     __syncthreads();
+    if (CHAIN) {
+        if (ctx->has_in) {                        // chunk 0 keeps the inlet carry it was given
+            carry.P = sh.cin[buf][RMT_V];
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) carry.up[i] = real(sh.cin[buf][i]);
+        }
+        ctx->abort = sh.abort[buf];
+        if (ctx->has_in && threadIdx.x == 0)      // record consumed (it sits in LDS now)
+            __hip_atomic_store(ctx->sync_in + 16, ctx->q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // pressure entering this wave = carry.P pushed through the totals of the waves before it
     preal pw = carry.P;
     for (int w = 0; w < wave; ++w) pw = sh.tot_a[buf][w] * pw + sh.tot_b[buf][w];
@@ -396,6 +468,21 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
         carry.P = pe;
 #pragma unroll
         for (int i = 0; i < RMT_V; ++i) carry.up[i] = sh.bnd[buf][RMT_NW - 1][i];
+    }
+    if (CHAIN) {
+        if (ctx->has_out && wave == RMT_NW - 1 && !ctx->abort) {     // publish this stage's record
+            const preal pe = sh.tot_a[buf][wave] * pw + sh.tot_b[buf][wave];
+            if (lane <= RMT_V) {                  // sc1 (write-through) stores, drained before the flag
+                const double v = (lane == RMT_V) ? (double)pe : (double)sh.bnd[buf][RMT_NW - 1][lane < RMT_V ? lane : 0];
+                __hip_atomic_store((unsigned long long*)ctx->slots_out +
+                                       (size_t)(ctx->q % RMT_CHAIN_DEPTH) * (RMT_V + 1) + lane,
+                                   (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(ctx->sync_out, ctx->q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -567,6 +654,121 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
     if (lflag) atomicOr(&flags[e], lflag);
 #undef Y0
 #undef ACC
+}
+
+// ===================================================================== kernel: RK4 on chip, chained workgroups
+// Same on-chip stepper for N > RMT_BLOCK*RMT_NPT (or to spread one reactor over several CUs):
+// reactor e is cut into C chunks of RMT_NODES_WG nodes; the grid is T teams of C workgroups
+// (T*C <= number of CUs, so every workgroup is resident), team t integrates reactors
+// t, t+T, t+2T, ...  The hand-over between consecutive chunks is described at RmtChainCtx.
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_chain(
+        real* __restrict__ y, const double* __restrict__ members, const int N, const int E,
+        const int C, const int T, const double h_, const long long nsteps,
+        unsigned long long* __restrict__ sync, double* __restrict__ slots,
+        unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+#if RMT_LDS_STATE >= 1
+    __shared__ real s_y0[RMT_V][RMT_NODES_WG];
+#endif
+#if RMT_LDS_STATE >= 2
+    __shared__ real s_acc[RMT_V][RMT_NODES_WG];
+#endif
+    const int team = blockIdx.x / C, c = blockIdx.x % C;
+    RmtChainCtx ctx;
+    ctx.has_in = c > 0;
+    ctx.has_out = c < C - 1;
+    const size_t link = (size_t)team * C + c;
+    ctx.sync_in = sync + (link - (c > 0 ? 1 : 0)) * RMT_SYNC_STRIDE;
+    ctx.sync_out = sync + link * RMT_SYNC_STRIDE;
+    ctx.slots_in = slots + (link - (c > 0 ? 1 : 0)) * RMT_CHAIN_DEPTH * (RMT_V + 1);
+    ctx.slots_out = slots + link * RMT_CHAIN_DEPTH * (RMT_V + 1);
+    ctx.q = 0ull;
+    ctx.abort = 0;
+    const int node0 = c * RMT_NODES_WG + (int)threadIdx.x * RMT_NPT;
+    int nvalid = N - node0;
+    nvalid = nvalid < 0 ? 0 : (nvalid > RMT_NPT ? RMT_NPT : nvalid);
+    const int lnode0 = (int)threadIdx.x * RMT_NPT;
+    const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);
+    bool dead = false;
+    for (int e = team; e < E && !dead; e += T) {
+        RmtMember m;
+        rmt_load_member(members + (size_t)e * RMT_NM, m);
+        RmtCarry carry;
+        rmt_carry_inlet(m, carry);
+        real* ye = y + (size_t)e * RMT_V * N;
+        real ys[RMT_NPT][RMT_V], k[RMT_NPT][RMT_V];
+#if RMT_LDS_STATE < 1
+        real y0[RMT_NPT][RMT_V];
+#define Y0(j, i) y0[j][i]
+#else
+#define Y0(j, i) s_y0[i][lnode0 + (j)]
+#endif
+#if RMT_LDS_STATE < 2
+        real acc[RMT_NPT][RMT_V];
+#define ACC(j, i) acc[j][i]
+#else
+#define ACC(j, i) s_acc[i][lnode0 + (j)]
+#endif
+#pragma unroll
+        for (int j = 0; j < RMT_NPT; ++j) {
+            rmt_safe_state(m, ys[j]);
+            if (j < nvalid) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) ys[j][i] = ye[(size_t)i * N + node0 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) Y0(j, i) = ys[j][i];
+        }
+        rmt_flags_t flag;
+        rmt_flags_clear(flag);
+        unsigned lflag = 0u;
+        for (long long step = 0; step < nsteps && !dead; ++step) {
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) {
+                ctx.q += 1ull;
+                rmt_rhs_block<RMT_NPT, false, true>(m, sh, s & 1, ys, nvalid, carry, k, flag, &ctx);
+                if (ctx.abort) { dead = true; break; }
+                if (s < 3) {
+                    const real cn = (s == 2) ? h : hh;
+                    const real wk = (s == 0) ? real(1) : real(2);
+#pragma unroll
+                    for (int j = 0; j < RMT_NPT; ++j)
+#pragma unroll
+                        for (int i = 0; i < RMT_V; ++i) {
+                            ACC(j, i) = (s == 0) ? k[j][i] : ACC(j, i) + wk * k[j][i];
+                            ys[j][i] = Y0(j, i) + k[j][i] * cn;
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < RMT_NPT; ++j)
+#pragma unroll
+                        for (int i = 0; i < RMT_V; ++i) {
+                            const real yn = Y0(j, i) + h6 * (ACC(j, i) + k[j][i]);
+                            Y0(j, i) = yn;
+                            ys[j][i] = yn;
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RMT_NPT; ++j) {
+            if (j < nvalid) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) ye[(size_t)i * N + node0 + j] = ys[j][i];
+                lflag |= rmt_finite_flag(ys[j]);
+            }
+        }
+        lflag |= rmt_flags_bits(flag);
+        if (dead) lflag |= RMT_FLAG_STEP;
+        if (lflag) atomicOr(&flags[e], lflag);
+#undef Y0
+#undef ACC
+    }
+    if (dead && threadIdx.x == 0) {       // let the rest of the chain drain
+        __hip_atomic_store(ctx.sync_out, RMT_CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > 0)
+            __hip_atomic_store(ctx.sync_in + 16, RMT_CHAIN_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ===================================================================== kernel: RK4, state in memory

@@ -40,7 +40,11 @@ struct rmt_n2_handle {
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
-                  f_rk45_mem = nullptr, f_multistep = nullptr;
+                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr;
+    unsigned long long* d_sync = nullptr;
+    double* d_slots = nullptr;
+    size_t chain_links = 0;
+    int n_cus = 0;
     double* d_members = nullptr;
     unsigned* d_flags = nullptr;
     void* d_work = nullptr;
@@ -151,7 +155,10 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         h->f_rk45_mem = nullptr;
     if (hipModuleGetFunction(&h->f_multistep, h->module, "rmt_n2_multistep_mem") != hipSuccess)
         h->f_multistep = nullptr;
+    if (hipModuleGetFunction(&h->f_rk4_chain, h->module, "rmt_n2_rk4_chain") != hipSuccess)
+        h->f_rk4_chain = nullptr;
     (void)hipGetLastError();
+    CREATE_OK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
     CREATE_OK(hipMalloc((void**)&h->d_members, mbytes));
     CREATE_OK(hipMemcpy(h->d_members, p->members, mbytes, hipMemcpyHostToDevice));
@@ -169,6 +176,8 @@ extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (h->d_members) (void)hipFree(h->d_members);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_sync) (void)hipFree(h->d_sync);
+    if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->module) (void)hipModuleUnload(h->module);
@@ -183,7 +192,7 @@ extern "C" int rmt_n2_set_stream(rmt_n2_handle* h, void* s) {
 
 extern "C" int rmt_n2_set_mode(rmt_n2_handle* h, int mode) {
     if (!h) return fail("null handle");
-    if (mode < 0 || mode > 2) return fail("mode must be 0 (auto), 1 (registers) or 2 (memory)");
+    if (mode < 0 || mode > 3) return fail("mode must be 0 (auto), 1 (on-chip), 2 (memory) or 3 (chained)");
     h->mode = mode;
     return 0;
 }
@@ -210,10 +219,10 @@ static int ensure_work(rmt_n2_handle* h, size_t arrays) {
     return 0;
 }
 
-static int launch(rmt_n2_handle* h, hipFunction_t f, void** args) {
+static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1) {
     HIP_OK(hipEventRecord(h->ev0, h->stream));
-    HIP_OK(hipModuleLaunchKernel(f, (unsigned)h->E, 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args,
-                                 nullptr));
+    HIP_OK(hipModuleLaunchKernel(f, (unsigned)(grid > 0 ? grid : h->E), 1, 1, (unsigned)h->block, 1, 1, 0,
+                                 h->stream, args, nullptr));
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return 0;
@@ -251,6 +260,28 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&dt, (void*)&ns,
                         (void*)&h->d_flags};
         return launch(h, h->f_rk4_reg, args);
+    }
+    // chained workgroups: C chunks per reactor, T teams, every workgroup resident (T*C <= #CUs)
+    const int W = h->block * h->npt;
+    int C = (h->N + W - 1) / W;
+    const bool can_chain = h->f_rk4_chain && C >= 2 && C <= h->n_cus;
+    if (h->mode == 3 && !can_chain)
+        return fail("chained stepper needs 2 <= chunks (%d) <= CUs (%d)", C, h->n_cus);
+    if (h->mode == 3 || (h->mode == 0 && can_chain)) {
+        int T = h->n_cus / C;
+        if (T > h->E) T = h->E;
+        const size_t links = (size_t)T * C;
+        if (h->chain_links < links) {
+            if (h->d_sync) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->d_sync)); HIP_OK(hipFree(h->d_slots)); }
+            h->d_sync = nullptr; h->d_slots = nullptr; h->chain_links = 0;
+            HIP_OK(hipMalloc((void**)&h->d_sync, links * 32 * sizeof(unsigned long long)));
+            HIP_OK(hipMalloc((void**)&h->d_slots, links * 8 * (size_t)(h->V + 1) * sizeof(double)));
+            h->chain_links = links;
+        }
+        HIP_OK(hipMemsetAsync(h->d_sync, 0, links * 32 * sizeof(unsigned long long), h->stream));
+        void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
+                        (void*)&dt, (void*)&ns, (void*)&h->d_sync, (void*)&h->d_slots, (void*)&h->d_flags};
+        return launch(h, h->f_rk4_chain, args, T * C);
     }
     if (ensure_work(h, 3)) return 1;
     void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,

@@ -18,16 +18,20 @@ from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 DEVICE_IVPS = ("hip-rk4", "hip-rk45", "AM", "hip-ab3")
 
 
-def choose_geometry(N, V, fp32=False):
-    """(block, nodes_per_thread) of the generated kernels for a reactor of N nodes.
-    Register-resident steppers need N <= block*npt; beyond that the memory-resident ones run with
-    256-thread workgroups.  The table is what measured fastest on MI355X."""
+def choose_geometry(N, V, fp32=False, E=None):
+    """(block, nodes_per_thread) of the generated kernels for E reactors of N nodes.
+    The on-chip stepper holds block*npt nodes per workgroup; longer reactors are chained over
+    several workgroups (rmt_n2_rk4_chain).  The table is what measured fastest on MI355X
+    (profiles/round1_chain.md, round1_shapes.md):
+      * big ensembles: 512 threads x 2 nodes (1024-node chunks, 2 waves/SIMD, y_n/acc in LDS);
+      * little total work (E*N <= 32768 nodes, e.g. ONE reactor): 128-node chunks so that a
+        single reactor spreads over up to 256 CUs (14.8 us/step at N=4096 vs 199 us on one CU)."""
+    if N > 256 and E is not None and E*N <= 256*128:
+        return 128, 1
     for block in (64, 128, 256, 512):
         if N <= block:
             return block, 1
-    if N <= 1024:
-        return (512, 2) if V <= 8 else (1024, 1)
-    return 256, 1
+    return (512, 2) if V <= 8 else (512, 1)
 
 
 def _torch():
@@ -51,7 +55,7 @@ class N2Device:
         assert members.shape[1] == plan.MEMBER_FIXED + mech.S
         self.E = members.shape[0]
         self.members = members
-        b, n = choose_geometry(self.N, mech.V, fp32)
+        b, n = choose_geometry(self.N, mech.V, fp32, self.E)
         self.block, self.npt = int(block or b), int(npt or n)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         tpl = hipbind.kernel_template()
@@ -85,7 +89,7 @@ class N2Device:
         hipbind.check(hipbind.lib().rmt_n2_set_stream(self.h, C.c_void_p(s)))
 
     def set_mode(self, mode):
-        hipbind.check(hipbind.lib().rmt_n2_set_mode(self.h, {"auto": 0, "reg": 1, "mem": 2}[mode]))
+        hipbind.check(hipbind.lib().rmt_n2_set_mode(self.h, {"auto": 0, "reg": 1, "mem": 2, "chain": 3}[mode]))
 
     def close(self):
         if getattr(self, "h", None):
@@ -201,9 +205,10 @@ def _progress(i, total, quiet):
 
 
 def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None, defines=None,
-                      arch="gfx950"):
-    """Code object for (mechanism, mesh size) - what ensemble rank 0 compiles and broadcasts."""
-    b, n = choose_geometry(N, mech.V, fp32)
+                      arch="gfx950", E=None):
+    """Code object for (mechanism, mesh size, members per rank) - what ensemble rank 0 compiles
+    and broadcasts; pass the same E/block/npt/lds_state/defines to N2Device(code=...)."""
+    b, n = choose_geometry(N, mech.V, fp32, E)
     block, npt = int(block or b), int(npt or n)
     ls = mech.lds_state(fp32, block, npt, lds_state)
     tpl = hipbind.kernel_template()

@@ -27,7 +27,8 @@ def run(name, N, E, steps, mode="auto", dt=2e-6, **kw):
     dev.rk4(y, dt, steps)
     ms = dev.last_kernel_ms()
     fl = dev.status()
-    kern = "reg" if (mode != "mem" and N <= dev.block*dev.npt) else "mem"
+    W = dev.block*dev.npt
+    kern = "mem" if mode == "mem" else ("reg" if N <= W else "chain[%d]" % (-(-N//W)))
     rate = E*N*steps/(ms/1e3)
     print("| %s | %d | %d | rk4_%s %dx%d lds%d | %d | %.3f | %.3e | %s |" % (
         name, N, E, kern, dev.block, dev.npt, dev.lds_state, steps, ms, rate, "ok" if not fl.any() else hex(int(fl.max()))),

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_OPS_PER_NODE_STEP = 2106   # v_*_f64 instructions per node per RK4 step in rmt_n2_rk4_reg (DME, block 512 x 2)
+FP64_OPS_PER_NODE_STEP = 1834   # v_*_f64 instructions per node per RK4 step in rmt_n2_rk4_reg (DME, block 512 x 2)
 N_NODES = 1024
 MEMBERS_PER_GPU = 256
 DT = 2e-6
@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--block", type=int, default=None)
     ap.add_argument("--npt", type=int, default=None)
     ap.add_argument("--lds", type=int, default=None, help="RK4 vectors kept in LDS (0,1,2)")
+    ap.add_argument("--no-specialize", action="store_true", help="keep all member fields run-time")
     ap.add_argument("--define", action="append", default=[], help="kernel tuning macro NAME=VALUE")
     args = ap.parse_args()
 
@@ -128,12 +129,15 @@ def main():
     defines = dict(d.split('=', 1) for d in args.define)
     ens = DistributedEnsemble(
         mech, inputs, n_nodes, device=torch.device("cuda", local),
-        compile_fn=lambda: compile_mechanism(mech, n_nodes, block=args.block, npt=args.npt,
-                                             lds_state=args.lds, defines=defines, E=E))
+        compile_fn=lambda mdef: compile_mechanism(mech, n_nodes, block=args.block, npt=args.npt,
+                                                  lds_state=args.lds, defines={**defines, **mdef}, E=E))
     rows, IV = ens.rows, ens.IV
     assert rows.shape[0] == E
+    if args.no_specialize:
+        ens.member_defines.clear()
     dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds,
-                   defines=defines, code=ens.code)
+                   defines={**defines, **ens.member_defines}, specialize=False,
+                   code=None if args.no_specialize else ens.code)
     dev.set_mode(args.mode)
     y = dev.to_device(IV)
 

@@ -14,10 +14,13 @@
 #define __device__
 #define __forceinline__ inline
 #define __restrict__
+#ifndef INFINITY
+#define INFINITY __builtin_inf()
+#endif
 using std::trunc;
 #include RMT_GENERATED_SOURCE
 
-static void emu_rhs_one(const RmtMember& m, const real* y, real* dydt, int N, unsigned& flag) {
+static void emu_rhs_one(const RmtMember& m, const real* y, real* dydt, int N, rmt_flags_t& flag) {
     preal P = m.p0;
     real up[RMT_V];
     for (int i = 0; i < RMT_S; ++i) up[i] = m.cin[i];
@@ -56,9 +59,10 @@ extern "C" void emu_rhs(const real* y, real* dydt, const double* members, int N,
     for (int e = 0; e < E; ++e) {
         RmtMember m;
         rmt_load_member(members + (size_t)e * RMT_NM, m);
-        unsigned f = 0;
+        rmt_flags_t f;
+        rmt_flags_clear(f);
         emu_rhs_one(m, y + (size_t)e * RMT_V * N, dydt + (size_t)e * RMT_V * N, N, f);
-        flags[e] |= f;
+        flags[e] |= rmt_flags_bits(f);
     }
 }
 
@@ -72,7 +76,8 @@ extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_,
         const size_t n = (size_t)RMT_V * N;
         real* y0 = y + e * n;
         std::vector<real> ys(n), k(n), acc(n);
-        unsigned f = 0;
+        rmt_flags_t f;
+        rmt_flags_clear(f);
         for (long long s = 0; s < nsteps; ++s) {
             emu_rhs_one(m, y0, k.data(), N, f);
             for (size_t i = 0; i < n; ++i) { acc[i] = k[i]; ys[i] = y0[i] + k[i] * hh; }
@@ -83,6 +88,6 @@ extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_,
             emu_rhs_one(m, ys.data(), k.data(), N, f);
             for (size_t i = 0; i < n; ++i) y0[i] += h6 * (acc[i] + k[i]);
         }
-        flags[e] |= f;
+        flags[e] |= rmt_flags_bits(f);
     }
 }

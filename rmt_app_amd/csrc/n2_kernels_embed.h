@@ -65,9 +65,6 @@ typedef double preal;   // the pressure scan is always carried in fp64
 #define RMT_TREF real(298.15)
 
 // ------------------------------------------------------------------ math wrappers
-__device__ __forceinline__ double rmt_exp(double x) { return exp(x); }
-__device__ __forceinline__ double rmt_exp10(double x) { return exp10(x); }
-__device__ __forceinline__ double rmt_exp2(double x) { return exp2(x); }
 __device__ __forceinline__ double rmt_expm1(double x) { return expm1(x); }
 __device__ __forceinline__ double rmt_log10(double x) { return log10(x); }
 __device__ __forceinline__ double rmt_log2(double x) { return log2(x); }
@@ -107,12 +104,50 @@ __device__ __forceinline__ float rmt_max(float a, float b) { return fmaxf(a, b);
 
 // ---- status flags ---------------------------------------------------------------------------
 // The generated kinetics test the conditions on which Python would raise (log(<=0), x/0, exp
-// overflow ...).  On the device each test is one v_cmp into an SGPR pair that is OR-ed into a
-// wave-wide lane mask with a scalar instruction (no per-lane select/or VALU work); the masks
-// are collapsed to the per-reactor status bits once, at the end of the launch.
+// overflow ...) through RMT_CHECK_POS / _NONNEG / _DEN / _EXP (and the generic RMT_CHECK).
+// RMT_FLAGS_MODE 0 (device default): one v_cmp into an SGPR pair OR-ed into a wave-wide lane mask
+//   with a scalar instruction; masks are collapsed to status bits at the end of the launch.
+// RMT_FLAGS_MODE 1 (host emulation; selectable on the device): one fp64 min/max into per-lane
+//   running extremes.  On gfx950 this cost 8 more live VGPRs and pushed the 512x2 kernel into
+//   scratch (10.1 -> 6.9 G node-steps/s), so it is not the default there.
+#define RMT_EXP_LIMIT 709.782712893384
+#ifndef RMT_FLAGS_MODE
 #ifdef RMT_HOST_EMULATION
-typedef unsigned rmt_flags_t;
-#define RMT_CHECK(f, cond, bit) (f) |= ((cond) ? (bit) : 0u)
+#define RMT_FLAGS_MODE 1
+#else
+#define RMT_FLAGS_MODE 0
+#endif
+#endif
+#if RMT_FLAGS_MODE == 1
+struct rmt_flags_t {
+    real pos_min;       // smallest argument that must be  > 0  (log)
+    real nn_min;        // smallest argument that must be >= 0  (sqrt)
+    real den_min;       // smallest |denominator|
+    real exp_max;       // largest exp() argument
+    unsigned bits;      // anything else (pow domain), per lane
+};
+__device__ __forceinline__ void rmt_flags_clear(rmt_flags_t& f) {
+    f.pos_min = f.nn_min = f.den_min = real(__builtin_inf());
+    f.exp_max = real(-__builtin_inf());
+    f.bits = 0u;
+}
+__device__ __forceinline__ void rmt_flags_merge(rmt_flags_t& into, const rmt_flags_t& f) {
+    into.pos_min = rmt_min(into.pos_min, f.pos_min);
+    into.nn_min = rmt_min(into.nn_min, f.nn_min);
+    into.den_min = rmt_min(into.den_min, f.den_min);
+    into.exp_max = rmt_max(into.exp_max, f.exp_max);
+    into.bits |= f.bits;
+}
+__device__ __forceinline__ unsigned rmt_flags_bits(const rmt_flags_t& f) {
+    return f.bits | ((f.pos_min <= real(0) || f.nn_min < real(0)) ? RMT_FLAG_DOMAIN : 0u) |
+           ((f.den_min == real(0)) ? RMT_FLAG_DIV0 : 0u) |
+           ((f.exp_max > real(RMT_EXP_LIMIT)) ? RMT_FLAG_OVERFLOW : 0u);
+}
+#define RMT_CHECK_POS(f, x) (f).pos_min = rmt_min((f).pos_min, (x))
+#define RMT_CHECK_NONNEG(f, x) (f).nn_min = rmt_min((f).nn_min, (x))
+#define RMT_CHECK_DEN(f, x) (f).den_min = rmt_min((f).den_min, rmt_abs(x))
+#define RMT_CHECK_EXP(f, x) (f).exp_max = rmt_max((f).exp_max, (x))
+#define RMT_CHECK(f, cond, bit) (f).bits |= ((cond) ? (bit) : 0u)
 #else
 struct rmt_flags_t { unsigned long long dom, div0, ovf; };
 template <unsigned BIT>
@@ -122,17 +157,20 @@ __device__ __forceinline__ void rmt_check(rmt_flags_t& f, const bool c) {
     else if (BIT == RMT_FLAG_DIV0) f.div0 |= m;
     else f.ovf |= m;
 }
-#define RMT_CHECK(f, cond, bit) rmt_check<bit>(f, (cond))
 __device__ __forceinline__ void rmt_flags_clear(rmt_flags_t& f) { f.dom = f.div0 = f.ovf = 0ull; }
-__device__ __forceinline__ void rmt_flags_merge(rmt_flags_t& into, const rmt_flags_t& f,
-                                                const unsigned long long lanes) {
-    into.dom |= f.dom & lanes;
-    into.div0 |= f.div0 & lanes;
-    into.ovf |= f.ovf & lanes;
+__device__ __forceinline__ void rmt_flags_merge(rmt_flags_t& into, const rmt_flags_t& f) {
+    into.dom |= f.dom;
+    into.div0 |= f.div0;
+    into.ovf |= f.ovf;
 }
 __device__ __forceinline__ unsigned rmt_flags_bits(const rmt_flags_t& f) {
     return (f.dom ? RMT_FLAG_DOMAIN : 0u) | (f.div0 ? RMT_FLAG_DIV0 : 0u) | (f.ovf ? RMT_FLAG_OVERFLOW : 0u);
 }
+#define RMT_CHECK(f, cond, bit) rmt_check<bit>(f, (cond))
+#define RMT_CHECK_POS(f, x) rmt_check<RMT_FLAG_DOMAIN>(f, (x) <= real(0))
+#define RMT_CHECK_NONNEG(f, x) rmt_check<RMT_FLAG_DOMAIN>(f, (x) < real(0))
+#define RMT_CHECK_DEN(f, x) rmt_check<RMT_FLAG_DIV0>(f, (x) == real(0))
+#define RMT_CHECK_EXP(f, x) rmt_check<RMT_FLAG_OVERFLOW>(f, (x) > real(RMT_EXP_LIMIT))
 #endif
 
 // ---- lean fp64 division / reciprocal / log (RMT_FAST_MATH, default on) -----------------------
@@ -177,6 +215,55 @@ __device__ __forceinline__ double rmt_rcp(double b) { return 1.0 / b; }
 __device__ __forceinline__ double rmt_div(double a, double b) { return a / b; }
 __device__ __forceinline__ double rmt_log(double x) { return log(x); }
 #endif
+#if RMT_FAST_MATH && !defined(RMT_HOST_EMULATION)
+// exp(x) = 2^m * 2^(j/64) * e^r,  k = rint(x*64/ln2) = 64 m + j,  |r| <= ln2/128: a 64-entry table
+// (staged in LDS by rmt_math_init) and a degree-5 polynomial - 12 fp64 ops against 19 + 6 range
+// selects in the ocml version (the exp is ~40 % of the DME kernel's fp64 work).  Overflow is
+// flagged by the generated checks before the call; results below 2^-1022 flush through ldexp.
+__shared__ double rmt_exp_lds[64];
+__device__ static const double RMT_EXP_TAB[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0,
+};
+__device__ __forceinline__ void rmt_math_init() {
+    if (threadIdx.x < 64) rmt_exp_lds[threadIdx.x] = RMT_EXP_TAB[threadIdx.x];
+    __syncthreads();
+}
+__device__ __forceinline__ double rmt_exp(double x) {
+    const double kd = __builtin_rint(x * 92.33248261689366);            // 64/ln2
+    const int k = (int)kd;
+    double r = fma(-kd, 0.010830424696249145, x);                       // ln2/64 hi
+    r = fma(-kd, 3.623510646634843e-19, r);                             // ln2/64 lo
+    double p = fma(r, 8.3333333333333332e-03, 4.1666666666666664e-02);  // 1/120, 1/24
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = p * r;
+    p = fma(p, r, r);                                                   // e^r - 1
+    const double t = rmt_exp_lds[k & 63];
+    return __builtin_ldexp(fma(t, p, t), k >> 6);
+}
+__device__ __forceinline__ double rmt_exp10(double x) { return rmt_exp(x * 2.302585092994046); }
+__device__ __forceinline__ double rmt_exp2(double x) { return rmt_exp(x * 0.6931471805599453); }
+#else
+__device__ __forceinline__ void rmt_math_init() {}
+__device__ __forceinline__ double rmt_exp(double x) { return exp(x); }
+__device__ __forceinline__ double rmt_exp10(double x) { return exp10(x); }
+__device__ __forceinline__ double rmt_exp2(double x) { return exp2(x); }
+#endif
 __device__ __forceinline__ float rmt_rcp(float b) { return 1.0f / b; }
 __device__ __forceinline__ float rmt_div(float a, float b) { return a / b; }
 
@@ -189,24 +276,95 @@ struct RmtMember {
     real cin[RMT_S];
 };
 
+// A member field whose value is identical for every reactor of the launch can be baked into the
+// kernel as a literal (prelude: #define RMT_MC_<FIELD> value): literals are rematerialised with
+// s_mov instead of occupying (and spilling) SGPRs for the whole time loop.
 __device__ __forceinline__ void rmt_load_member(const double* __restrict__ row, RmtMember& m) {
+#ifdef RMT_MC_CMAX
+    m.cmax = real(RMT_MC_CMAX);
+#else
     m.cmax = real(row[M_CMAX]);
+#endif
+#ifdef RMT_MC_TF
+    m.tf = real(RMT_MC_TF);
+#else
     m.tf = real(row[M_TF]);
+#endif
+#ifdef RMT_MC_THETA_IN
+    m.theta_in = real(RMT_MC_THETA_IN);
+#else
     m.theta_in = real(row[M_THETA_IN]);
+#endif
+#ifdef RMT_MC_RHO_K
+    m.rho_k = real(RMT_MC_RHO_K);
+#else
     m.rho_k = real(row[M_RHO_K]);
+#endif
+#ifdef RMT_MC_INV_CP0
+    m.inv_cp0 = real(RMT_MC_INV_CP0);
+#else
     m.inv_cp0 = real(row[M_INV_CP0]);
+#endif
+#ifdef RMT_MC_F1
+    m.f1 = real(RMT_MC_F1);
+#else
     m.f1 = real(row[M_F1]);
+#endif
+#ifdef RMT_MC_FT
+    m.ft = real(RMT_MC_FT);
+#else
     m.ft = real(row[M_FT]);
+#endif
+#ifdef RMT_MC_INV_DZ
+    m.inv_dz = real(RMT_MC_INV_DZ);
+#else
     m.inv_dz = real(row[M_INV_DZ]);
+#endif
+#ifdef RMT_MC_INV_MACOTE
+    m.inv_macote = real(RMT_MC_INV_MACOTE);
+#else
     m.inv_macote = real(row[M_INV_MACOTE]);
+#endif
+#ifdef RMT_MC_INV_HECOTE
+    m.inv_hecote = real(RMT_MC_INV_HECOTE);
+#else
     m.inv_hecote = real(row[M_INV_HECOTE]);
+#endif
+#ifdef RMT_MC_UA
+    m.ua = real(RMT_MC_UA);
+#else
     m.ua = real(row[M_UA]);
+#endif
+#ifdef RMT_MC_TM
+    m.tm = real(RMT_MC_TM);
+#else
     m.tm = real(row[M_TM]);
+#endif
+#ifdef RMT_MC_P0
+    m.p0 = RMT_MC_P0;
+#else
     m.p0 = row[M_P0];
+#endif
+#ifdef RMT_MC_ALPHA_K
+    m.alpha_k = RMT_MC_ALPHA_K;
+#else
     m.alpha_k = row[M_ALPHA_K];
+#endif
+#ifdef RMT_MC_BETA
+    m.beta = RMT_MC_BETA;
+#else
     m.beta = row[M_BETA];
+#endif
+#ifdef RMT_MC_CIN
+    {
+        const double cin_[RMT_S] = RMT_MC_CIN;
+#pragma unroll
+        for (int i = 0; i < RMT_S; ++i) m.cin[i] = real(cin_[i]);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < RMT_S; ++i) m.cin[i] = real(row[M_CIN + i]);
+#endif
 }
 
 // ------------------------------------------------------------------ node physics
@@ -216,6 +374,7 @@ struct RmtNode {
     real x[RMT_S];
     real C[RMT_S];
     real T, M;
+    real MoT;      // M/T, shared by the Ergun coefficient and the EOS density
 };
 
 __device__ __forceinline__ preal rmt_node_pre(const RmtMember& m, const real* __restrict__ ys,
@@ -241,7 +400,9 @@ __device__ __forceinline__ preal rmt_node_pre(const RmtMember& m, const real* __
     nd.T = ys[RMT_S] * m.tf + m.tf;                       // :3914
 #endif
     // P[z+1] = P[z] + dz*(-(ergA*ergB + 1.75*rho*v^2/dp*ergD)),  rho = P*M/(R*T)   (:3964-3979)
-    return preal(1) - m.alpha_k * rmt_div(preal(nd.M), preal(nd.T));
+    const preal mot = rmt_div(preal(nd.M), preal(nd.T));
+    nd.MoT = real(mot);
+    return preal(1) - m.alpha_k * mot;
 }
 
 // Phase B (pressure known): kinetics, species source, Cp, heat of reaction, wall exchange,
@@ -251,35 +412,47 @@ __device__ __forceinline__ void rmt_node_post(const RmtMember& m, const RmtNode&
                                               const real* __restrict__ up, const preal Pz,
                                               real* __restrict__ k, rmt_flags_t& flag) {
     const real P = real(Pz);
-    real r[RMT_R];
-    rmt_kinetics(nd.T, P, nd.x, nd.C, r, flag);           // :3989-3992
-    real src[RMT_S];
-    rmt_species_source(r, src);                                         // :4000 (sparse nu^T r)
+    // (1) convective parts first: after this the stage state and the upstream values are dead,
+    //     which keeps the register footprint of the kinetics small.
 #pragma unroll
-    for (int i = 0; i < RMT_S; ++i) {
-        const real dcdz = (ys[i] - up[i]) * m.inv_dz;                   // :4086-4095
-        k[i] = m.f1 * (src[i] * m.inv_macote - dcdz);                   // :4098
-    }
+    for (int i = 0; i < RMT_S; ++i)
+        k[i] = -m.f1 * ((ys[i] - up[i]) * m.inv_dz);                    // :4086-4098, convective term
 #if !RMT_ISO
     const real T = nd.T;
-    real cpbar[RMT_S];
+    k[RMT_S] = -m.ft * ((ys[RMT_S] - up[RMT_S]) * m.inv_dz);            // :4104-4116
+    // (2) everything of the energy balance that does not need the rates
+    real hq[RMT_R];
     real cpm = real(0);
+    {
+        real cpbar[RMT_S];
 #pragma unroll
-    for (int i = 0; i < RMT_S; ++i) {
-        cpbar[i] = rmt_cp_mean(i, T);                                   // rmtThermo.py:52-75
-        cpm += nd.x[i] * cpbar[i];                                      // :4013
+        for (int i = 0; i < RMT_S; ++i) {
+            cpbar[i] = rmt_cp_mean(i, T);                               // rmtThermo.py:52-75
+            cpm += nd.x[i] * cpbar[i];                                  // :4013
+        }
+        real dcp[RMT_R];
+        rmt_reaction_dcp(cpbar, dcp);                                   // sparse nu cpbar
+#pragma unroll
+        for (int q = 0; q < RMT_R; ++q) hq[q] = dcp[q] * (T - RMT_TREF) + RMT_DH25[q];   // :4025-4028
     }
-    real dcp[RMT_R];
-    rmt_reaction_dcp(cpbar, dcp);                                       // sparse nu cpbar
+    const real qm = (m.tm == real(0)) ? real(0) : m.ua * (m.tm - T);    // rmtUtility.py:438-445
+    const real rho_s = (P * nd.MoT) * m.rho_k;                          // :3964-3966
+    const real cp_s = cpm * m.inv_cp0;                                  // :4016
+    const real gain = rmt_div(m.f1 * m.inv_hecote, rho_s * cp_s);       // const_T2/GaHeCoTe0, :4077,4118
+#endif
+    // (3) kinetics and the source terms
+    real r[RMT_R];
+    rmt_kinetics(nd.T, P, nd.x, nd.C, r, flag);                         // :3989-3992
+    real src[RMT_S];
+    rmt_species_source(r, src);                                         // :4000 (sparse nu^T r)
+    const real fm = m.f1 * m.inv_macote;
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) k[i] += fm * src[i];                // :4098
+#if !RMT_ISO
     real qr = real(0);
 #pragma unroll
-    for (int q = 0; q < RMT_R; ++q)
-        qr += r[q] * (dcp[q] * (T - RMT_TREF) + RMT_DH25[q]);           // :4025-4032
-    const real qm = (m.tm == real(0)) ? real(0) : m.ua * (m.tm - T);    // rmtUtility.py:438-445
-    const real rho_s = rmt_div(P * nd.M, T) * m.rho_k;                  // :3964-3966
-    const real cp_s = cpm * m.inv_cp0;                                  // :4016
-    const real dtdz = (ys[RMT_S] - up[RMT_S]) * m.inv_dz;               // :4104-4114
-    k[RMT_S] = rmt_div(m.f1 * ((qm - qr) * m.inv_hecote), rho_s * cp_s) - m.ft * dtdz;   // :4116-4126
+    for (int q = 0; q < RMT_R; ++q) qr += r[q] * hq[q];                 // :4032
+    k[RMT_S] += gain * (qm - qr);                                       // :4118-4126
 #endif
 }
 
@@ -509,6 +682,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rhs(
         const real* __restrict__ y, real* __restrict__ dydt, const double* __restrict__ members,
         const int N, unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+    rmt_math_init();
     const int e = blockIdx.x;
 #if RMT_MEMBER_LDS
     __shared__ RmtMember m;      // read back with broadcast ds_reads: frees ~2*(15+S) SGPRs
@@ -562,6 +736,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_reg(
         real* __restrict__ y, const double* __restrict__ members, const int N, const double h_,
         const long long nsteps, unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+    rmt_math_init();
 #if RMT_LDS_STATE >= 1
     __shared__ real s_y0[RMT_V][RMT_NODES_WG];
 #endif
@@ -667,6 +842,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_chain(
         unsigned long long* __restrict__ sync, double* __restrict__ slots,
         unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+    rmt_math_init();
 #if RMT_LDS_STATE >= 1
     __shared__ real s_y0[RMT_V][RMT_NODES_WG];
 #endif
@@ -780,6 +956,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk4_mem(
         const int N, const int E, const double h_, const long long nsteps,
         unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+    rmt_math_init();
     const int e = blockIdx.x;
 #if RMT_MEMBER_LDS
     __shared__ RmtMember m;      // read back with broadcast ds_reads: frees ~2*(15+S) SGPRs
@@ -879,6 +1056,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk45_mem(
         double* __restrict__ stats /* [E][4]: t_end, h_last, accepted(i64), rejected(i64) */,
         unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+    rmt_math_init();
     const int e = blockIdx.x;
     RmtMember m;
     rmt_load_member(members + (size_t)e * RMT_NM, m);
@@ -967,7 +1145,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_rk45_mem(
                     }
                 }
             }
-            rmt_flags_merge(flag, trial, ~0ull);
+            rmt_flags_merge(flag, trial);
         } else {
             ++nrej;
             fac = fmax(0.2, 0.9 * pow(err, -0.2));     // K1 = f(y) stays valid after a rejection
@@ -1055,6 +1233,7 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_multistep_mem(
         const int N, const int E, const double h_, const long long nsteps, const int method,
         unsigned* __restrict__ flags) {
     __shared__ RmtShared sh;
+    rmt_math_init();
     const int e = blockIdx.x;
     RmtMember m;
     rmt_load_member(members + (size_t)e * RMT_NM, m);

@@ -94,9 +94,10 @@ def gather_rows(local, counts, dst=0, group=None):
 class DistributedEnsemble:
     """Rank-local slice of an ensemble + the two collectives described in the module docstring.
 
-    ``make_stepper(mech, rows, code)`` builds the rank-local integrator from the member rows and
-    the (broadcast) code object; on the GPU box that is ``N2Device``; the CPU tests inject a stand-in
-    to exercise partitioning and communication without a device.
+    ``compile_fn(member_defines)`` runs on rank 0 only and returns the code object that every rank
+    then loads (``N2Device(..., defines={**defines, **ens.member_defines}, specialize=False,
+    code=ens.code)``); the CPU tests integrate with a stand-in to exercise partitioning and
+    communication without a device.
     """
 
     def __init__(self, mech, member_inputs, zNo, group=None, device=None, compile_fn=None):
@@ -115,8 +116,22 @@ class DistributedEnsemble:
         self.rows = np.array([r for _, r in pairs]).reshape(len(mine), plan.MEMBER_FIXED + mech.S)
         self.IV = np.array([plan.initial_state(nm, mech, zNo) for nm in self.named]).reshape(
             len(mine), mech.V*zNo)
+        # member fields that are identical over the WHOLE ensemble become kernel literals: agree on
+        # them across ranks (rank 0's values; a column counts only if every rank finds it uniform
+        # and equal to rank 0's)
+        vals, mask = plan.uniform_columns(self.rows)
+        if dist.is_initialized():
+            import torch
+            dev = device if device is not None else torch.device("cpu")
+            v0 = torch.tensor(vals, dtype=torch.float64, device=dev)
+            dist.broadcast(v0, src=0, group=group)
+            v0 = v0.cpu().numpy()
+            ok = torch.tensor((mask & (vals == v0)).astype(np.int32), device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            vals, mask = v0, ok.cpu().numpy().astype(bool)
+        self.member_defines = plan.uniform_member_defines(None, mech.S, vals, mask)
         # rank 0 compiles; everyone receives the identical code object
-        code = compile_fn() if (self.rank == 0 and compile_fn is not None) else b""
+        code = compile_fn(self.member_defines) if (self.rank == 0 and compile_fn is not None) else b""
         if dist.is_initialized():
             code = broadcast_bytes(code, 0, group, device)
         self.code = code

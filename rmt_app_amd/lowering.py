@@ -471,9 +471,9 @@ class Lowered:
 
         def lit(v):
             if math.isnan(v):
-                return "real(NAN)"
+                return "real(__builtin_nan(\"\"))"
             if math.isinf(v):
-                return "real(INFINITY)" if v > 0 else "real(-INFINITY)"
+                return "real(__builtin_inf())" if v > 0 else "real(-__builtin_inf())"
             r = repr(float(v))
             return "real(%s)" % r
 
@@ -496,19 +496,17 @@ class Lowered:
             elif op == "mul":
                 e = "%s * %s" % (A, B)
             elif op == "div":
-                pre.append("RMT_CHECK(flag, %s == real(0), %du);" % (B, FLAG_DIV0))
+                pre.append("RMT_CHECK_DEN(flag, %s);" % B)
                 e = "rmt_div(%s, %s)" % (A, B)
             elif op == "rcp":
-                pre.append("RMT_CHECK(flag, %s == real(0), %du);" % (A, FLAG_DIV0))
+                pre.append("RMT_CHECK_DEN(flag, %s);" % A)
                 e = "rmt_rcp(%s)" % A
             elif op == "expn":      # stands for 1/exp(A): Python raises if exp(A) overflows or is 0
-                pre.append("RMT_CHECK(flag, %s > real(%r), %du);" % (A, _EXP_MAX, FLAG_OVERFLOW))
-                pre.append("RMT_CHECK(flag, %s < real(%r), %du);" % (A, -745.1332191019411, FLAG_DIV0))
+                pre.append("RMT_CHECK_EXP(flag, rmt_abs(%s));" % A)
                 e = "rmt_exp(-%s)" % A
             elif op in ("exp10n", "exp2n"):
-                lim = {"exp10n": 308.2547155599167, "exp2n": 1024.0}[op]
-                pre.append("RMT_CHECK(flag, %s > real(%r), %du);" % (A, lim, FLAG_OVERFLOW))
-                pre.append("RMT_CHECK(flag, %s < real(%r), %du);" % (A, -lim - 15.0, FLAG_DIV0))
+                k = {"exp10n": math.log(10.0), "exp2n": math.log(2.0)}[op]
+                pre.append("RMT_CHECK_EXP(flag, rmt_abs(%s) * real(%r));" % (A, k))
                 e = "rmt_%s(-%s)" % (op[:-1], A)
             elif op == "neg":
                 e = "-%s" % A
@@ -531,8 +529,8 @@ class Lowered:
                         sqname = nm
                 prod = " * ".join(terms)
                 if b < 0:
-                    pre.append("RMT_CHECK(flag, %s == real(0), %du);" % (A, FLAG_DIV0))
-                    e = "real(1) / (%s)" % prod
+                    pre.append("RMT_CHECK_DEN(flag, %s);" % A)
+                    e = "rmt_rcp(%s)" % prod
                 else:
                     e = prod
             elif op == "pow":
@@ -540,18 +538,18 @@ class Lowered:
                 pre.append("RMT_CHECK(flag, %s == real(0) && %s < real(0), %du);" % (A, B, FLAG_DIV0))
                 e = "rmt_pow(%s, %s)" % (A, B)
             elif op in ("log", "log10", "log2", "log1p"):
-                bad = "<= real(0)" if op != "log1p" else "<= real(-1)"
-                pre.append("RMT_CHECK(flag, %s %s, %du);" % (A, bad, FLAG_DOMAIN))
+                pre.append("RMT_CHECK_POS(flag, %s);" % (A if op != "log1p" else "(%s + real(1))" % A))
                 e = "rmt_%s(%s)" % (op, A)
             elif op == "sqrt":
-                pre.append("RMT_CHECK(flag, %s < real(0), %du);" % (A, FLAG_DOMAIN))
+                pre.append("RMT_CHECK_NONNEG(flag, %s);" % A)
                 e = "rmt_sqrt(%s)" % A
             elif op in ("exp", "exp10", "exp2", "expm1", "sinh", "cosh"):
                 lim = {"exp": _EXP_MAX, "expm1": _EXP_MAX, "sinh": 710.4758600739439,
                        "cosh": 710.4758600739439, "exp10": 308.2547155599167, "exp2": 1024.0}[op]
-                cond = ("%s > real(%r)" % (A, lim)) if op not in ("sinh", "cosh") else (
-                    "rmt_abs(%s) > real(%r)" % (A, lim))
-                pre.append("RMT_CHECK(flag, %s, %du);" % (cond, FLAG_OVERFLOW))
+                # one running maximum against exp's limit 709.78: scale the other bases' arguments
+                scale = {"exp10": math.log(10.0), "exp2": math.log(2.0)}.get(op)
+                arg = A if op not in ("sinh", "cosh") else "rmt_abs(%s)" % A
+                pre.append("RMT_CHECK_EXP(flag, %s);" % (arg if scale is None else "%s * real(%r)" % (arg, scale)))
                 e = "rmt_%s(%s)" % (op, A)
             elif op in ("sin", "cos", "tan", "tanh", "atan"):
                 e = "rmt_%s(%s)" % (op, A)
@@ -560,7 +558,7 @@ class Lowered:
             else:
                 raise LoweringError("no device emission for op %r" % op)
             for p in pre:
-                if p.startswith("RMT_CHECK("):
+                if p.startswith("RMT_CHECK"):
                     if p in seen_checks:
                         continue
                     seen_checks.add(p)

@@ -45,7 +45,7 @@ class N2Device:
     """One compiled mechanism + E packed member rows on one GPU."""
 
     def __init__(self, mech, members, N, fp32=False, block=None, npt=None, device=None,
-                 extra_opts="", lds_state=None, defines=None, code=None):
+                 extra_opts="", lds_state=None, defines=None, code=None, specialize=None):
         torch = _torch()
         self.torch = torch
         self.mech, self.N, self.fp32 = mech, int(N), bool(fp32)
@@ -61,6 +61,12 @@ class N2Device:
         tpl = hipbind.kernel_template()
         self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
         self.defines = dict(defines or {})
+        # sweep-invariant member fields become literals (frees SGPRs); a single reactor is NOT
+        # specialised by default - every new operating point would cost a 2-3 s JIT
+        if specialize is None:
+            specialize = self.E >= 2
+        if specialize:
+            self.defines.update(plan.uniform_member_defines(members, mech.S))
         src = mech.source(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
         key = mech.digest(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]

@@ -281,6 +281,28 @@ def member_constants(modelInput, mech, zNo):
     return named, row
 
 
+def uniform_columns(rows):
+    """(first row, bool mask of the columns that hold one value in every row)."""
+    rows = np.asarray(rows, dtype=float)
+    return rows[0].copy(), np.all(rows == rows[0], axis=0)
+
+
+def uniform_member_defines(rows, S, vals=None, mask=None):
+    """Prelude #defines (RMT_MC_<FIELD>) for the member fields that are identical in every row:
+    they become literals of the kernel (see rmt_load_member in csrc/n2_kernels.inc).  ``vals`` /
+    ``mask`` override the locally computed ones (multi-rank ensembles agree on them first)."""
+    if vals is None or mask is None:
+        vals, mask = uniform_columns(np.asarray(rows, dtype=float).reshape(-1, MEMBER_FIXED + S))
+    out = {}
+    for name, idx in MEMBER_FIELDS.items():
+        if name == "CIN":
+            if np.all(mask[idx:idx + S]):
+                out["RMT_MC_CIN"] = "{" + ", ".join(repr(float(v)) for v in vals[idx:idx + S]) + "}"
+        elif mask[idx]:
+            out["RMT_MC_" + name] = repr(float(vals[idx]))
+    return out
+
+
 def initial_state(named, mech, zNo):
     """IV2D flattened (pbHomoReactor.py:3483-3497)."""
     IV = np.zeros((mech.V, zNo))

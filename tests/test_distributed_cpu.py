@@ -37,10 +37,13 @@ def _worker(rank, world, port, n_members, N, out_path):
         from oracle.hostemu import HostEmu
         members = _members(n_members)
         mech = plan.Mechanism(members[0])
-        de = ENS.DistributedEnsemble(mech, members, N, compile_fn=lambda: compile_mechanism(mech, N))
+        de = ENS.DistributedEnsemble(mech, members, N,
+                                     compile_fn=lambda mdef: compile_mechanism(mech, N, defines=mdef))
+        assert "RMT_MC_P0" in de.member_defines and "RMT_MC_TF" not in de.member_defines   # T sweep
         assert de.code[:4] == b"\x7fELF"                       # every rank got rank 0's code object
         assert sum(de.counts) == n_members and de.hi - de.lo == de.counts[rank]
-        emu = HostEmu(mech.source(hipbind.kernel_template()), tag="dist", openmp=False)
+        emu = HostEmu(mech.source(hipbind.kernel_template(), defines=de.member_defines), tag="dist",
+                      openmp=False)
         y, flags = emu.rk4(de.IV, de.rows, N, 2e-6, 25)
         assert not flags.any()
         outlet = de.gather_outlet(torch.from_numpy(y))

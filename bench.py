@@ -182,7 +182,13 @@ def main():
                            "reg" if (args.mode != "mem" and n_nodes <= dev.block*dev.npt) else "mem",
                            dev.block, dev.npt, dev.lds_state)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved/HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved/HBM_PEAK_GBS,
+                         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+                         # profiles/round1_bench_rk4_reg.md): the state once each way, for ANY step
+                         # count - known only for the default workload, null otherwise
+                         "traffic": 3.0e7 if (E == MEMBERS_PER_GPU and n_nodes == N_NODES and
+                                              args.mode == "auto") else None,
+                         "traffic_unit": "bytes per launch (PMC)",
                          "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step,
                          "note": "state stays on chip for all steps of a launch; the limiter is fp64 "
                                  "VALU issue, see valu_fp64"},

@@ -23,6 +23,10 @@
  *   rmt_n2_rk45         - scipy.integrate.solve_ivp(funSet, t, IV, method=..., args=(paramsSet,))
  *                         at pbHomoReactor.py:3609-3610, restricted to an explicit embedded pair
  *                         (Dormand-Prince 5(4)) with per-reactor step control.
+ *   rmt_n2_ros4         - the same solve_ivp call site with a STIFF method (the reference's default is
+ *                         LSODA, pbHomoReactor.py:3576): linearly-implicit 4th-order Rosenbrock
+ *                         (Kaps-Rentrop/Shampine) with embedded error estimate and per-reactor
+ *                         step control; SURVEY.md section 8(f) rank 2.
  *   rmt_n2_status       - the exceptions Python raises inside the user lambdas / `raise` at
  *                         pbHomoReactor.py:3614-3626, as per-reactor flag words.
  *
@@ -102,6 +106,8 @@ int rmt_n2_rk4(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t ns
 /* method: 0 = AdBash3, 1 = PreCorr3 (needs nsteps >= 3, like the reference) */
 int rmt_n2_multistep(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t nsteps, int method);
 int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
+                double h0, int64_t max_steps, rmt_n2_stats* stats_out);
+int rmt_n2_ros4(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 /* copies the E flag words to host memory (synchronises the stream) and clears them on device */
 int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);

@@ -515,6 +515,11 @@ __device__ __forceinline__ int rmt_chain_wait(unsigned long long* word, const un
     }
 }
 
+struct RmtLocal {       // what a node's balances see of the rest of the reactor
+    preal P;            // pressure at the node
+    real up[RMT_V];     // clamped state of the upstream node (inlet values for node 0)
+};
+
 struct RmtCarry {       // workgroup-uniform hand-over between consecutive node blocks
     preal P;            // pressure at the first node of the block
     real up[RMT_V];     // clamped state of the node just upstream of the block (inlet for block 0)
@@ -536,7 +541,8 @@ template <int NPT, bool CARRY_OUT, bool CHAIN = false>
 __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh, const int buf,
                                               const real (&ys)[NPT][RMT_V], const int nvalid,
                                               RmtCarry& carry, real (&k)[NPT][RMT_V],
-                                              rmt_flags_t& flag, RmtChainCtx* ctx = nullptr) {
+                                              rmt_flags_t& flag, RmtChainCtx* ctx = nullptr,
+                                              RmtLocal* loc_out = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     RmtNode nd[NPT];
@@ -626,6 +632,11 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
     for (int j = 0; j < NPT; ++j) {
         // lanes beyond the reactor's end carry the (valid) inlet state, so their checks are not masked
         rmt_node_post(m, nd[j], ys[j], up, P, k[j], flag);
+        if (loc_out) {                                   // frozen neighbourhood of node j (Jacobian)
+            loc_out[j].P = P;
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) loc_out[j].up[i] = up[i];
+        }
         P = loc[j].a * P + loc[j].b;
         if (j + 1 < NPT) {
 #pragma unroll
@@ -1293,6 +1304,355 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_multistep_mem(
         }
     }
     lflag |= rmt_flags_bits(flag);
+    if (lflag) atomicOr(&flags[e], lflag);
+}
+
+// ===================================================================== kernel: stiff integrator (Rosenbrock), state in memory
+// SURVEY.md section 8(f) rank 2.  The explicit steppers are stability-limited to dt ~ 3e-6 s on
+// the hot DME bed (250 000 steps for 0.5 s).  This kernel is a linearly-implicit 4th-order
+// Rosenbrock method with an embedded 3rd-order error estimate - the Kaps-Rentrop scheme with
+// Shampine's parameters (gamma = 1/2; 3 RHS evaluations, 4 linear solves per step) - and
+// per-reactor step control like rmt_n2_rk45_mem.
+//   Jacobian: the method of lines RHS of node z depends on its own state, on the clamped state of
+// node z-1 (upwind) and - weakly - on all upstream nodes through the pressure march.  J is taken
+// as block lower-bidiagonal: D_z = d f_z / d y_z by forward differences of the node function at
+// frozen (P_z, upstream state), L_z = d f_z / d y_{z-1} = diag(F1/dz or FT/dz) (0 where the clamp
+// is active); the pressure coupling is dropped (measured: same step counts and accuracy as the
+// full finite-difference Jacobian, tools/ros_prototype.py).
+//   Solve (I/(gamma h) - J) x = b: per node x_z = Ainv_z (b_z + L_z x_{z-1}), Ainv_z the explicit
+// VxV inverse (Gauss-Jordan in registers); the upstream coupling is resolved by Jacobi sweeps
+// x <- p + Ainv L x_up whose contraction factor is <= c/(1/(gamma h) + c), c = F1/dz (h is capped
+// so that this is <= 1/2); node blocks are walked in order, so the block boundary value is exact.
+// work = 8 vector arrays [E][V][N] (F, G1..G4, stage state, new state, b) + Ainv [E][V*V][N] +
+// per-node clamp masks.
+#define RMT_ROS_GAM 0.5
+__device__ __forceinline__ void rmt_shift_up(RmtShared& sh, const int buf, const real (&x)[RMT_V],
+                                             const real (&carry_in)[RMT_V], real (&xup)[RMT_V],
+                                             real (&carry_out)[RMT_V]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < RMT_V; ++i) xup[i] = __shfl_up(x[i], 1);
+    if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < RMT_V; ++i) sh.bnd[buf][wave][i] = x[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < RMT_V; ++i) xup[i] = (wave == 0) ? carry_in[i] : sh.bnd[buf][wave - 1][i];
+    }
+#pragma unroll
+    for (int i = 0; i < RMT_V; ++i) carry_out[i] = sh.bnd[buf][RMT_NW - 1][i];
+}
+
+// in-place inverse of a VxV matrix held in registers (Gauss-Jordan, no pivoting: the matrix is
+// I/(gamma h) - D with a dominant positive diagonal); returns the smallest |pivot|
+__device__ __forceinline__ real rmt_invert(real (&a)[RMT_V][RMT_V]) {
+    real pmin = real(__builtin_inf());
+#pragma unroll
+    for (int p = 0; p < RMT_V; ++p) {
+        pmin = rmt_min(pmin, rmt_abs(a[p][p]));
+        const real ip = rmt_rcp(a[p][p]);
+        a[p][p] = real(1);
+#pragma unroll
+        for (int c = 0; c < RMT_V; ++c) a[p][c] *= ip;
+#pragma unroll
+        for (int r = 0; r < RMT_V; ++r) {
+            if (r != p) {
+                const real f = a[r][p];
+                a[r][p] = real(0);
+#pragma unroll
+                for (int c = 0; c < RMT_V; ++c) a[r][c] -= f * a[p][c];
+            }
+        }
+    }
+    return pmin;
+}
+
+// F = f(src) for all node blocks; if WITH_JAC also Ainv(h) and the clamp masks of the upwind coupling
+template <bool WITH_JAC>
+__device__ __forceinline__ void rmt_ros_eval(const RmtMember& m, RmtShared& sh, int& ph,
+                                             const real* src, real* dstF, real* ainv, unsigned* mask,
+                                             const int N, const real inv_gh, rmt_flags_t& flag,
+                                             real& pivmin) {
+    RmtCarry carry;
+    rmt_carry_inlet(m, carry);
+    for (int base = 0; base < N; base += RMT_BLOCK, ph ^= 1) {
+        const int node = base + (int)threadIdx.x;
+        const bool valid = node < N;
+        real ys[1][RMT_V], k[1][RMT_V];
+        rmt_safe_state(m, ys[0]);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) ys[0][i] = src[(size_t)i * N + node];
+        }
+        RmtLocal lc[1];
+        rmt_rhs_block<1, true, false>(m, sh, ph, ys, valid ? 1 : 0, carry, k, flag, nullptr,
+                                      WITH_JAC ? lc : nullptr);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) dstF[(size_t)i * N + node] = k[0][i];
+        }
+        if (WITH_JAC) {
+            real a[RMT_V][RMT_V];
+            rmt_flags_t scratch_flag;
+            rmt_flags_clear(scratch_flag);
+#pragma unroll
+            for (int c = 0; c < RMT_V; ++c) {                    // column c of D_z by a forward difference
+                real yp[RMT_V], kp[RMT_V];
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) yp[i] = ys[0][i];
+                const real d = real(1.5e-8) * rmt_max(rmt_abs(ys[0][c]), real(1e-3));
+                yp[c] += d;
+                const real id = rmt_rcp(yp[c] - ys[0][c]);
+                RmtNode ndp;
+                (void)rmt_node_pre(m, yp, ndp);
+                rmt_node_post(m, ndp, yp, lc[0].up, lc[0].P, kp, scratch_flag);
+#pragma unroll
+                for (int r = 0; r < RMT_V; ++r) a[r][c] = -(kp[r] - k[0][r]) * id;
+            }
+#pragma unroll
+            for (int i = 0; i < RMT_V; ++i) a[i][i] += inv_gh;   // A = I/(gamma h) - D
+            const real pv = rmt_invert(a);
+            if (valid) {
+                pivmin = rmt_min(pivmin, pv);
+#pragma unroll
+                for (int r = 0; r < RMT_V; ++r)
+#pragma unroll
+                    for (int c = 0; c < RMT_V; ++c) ainv[(size_t)(r * RMT_V + c) * N + node] = a[r][c];
+                unsigned mk = 0u;                                 // upwind coupling active? (:4093 clamp)
+                if (node > 0) {
+#pragma unroll
+                    for (int i = 0; i < RMT_S; ++i) mk |= (lc[0].up[i] > RMT_EPS) ? (1u << i) : 0u;
+#if !RMT_ISO
+                    mk |= 1u << RMT_S;
+#endif
+                }
+                mask[node] = mk;
+            }
+        }
+    }
+}
+
+// x = (I/(gamma h) - J)^-1 b with the stored inverses; b and x may alias
+__device__ __forceinline__ void rmt_ros_solve(const RmtMember& m, RmtShared& sh, int& ph,
+                                              const real* b, real* x, const real* ainv,
+                                              const unsigned* mask, const int N, const int sweeps) {
+    real carry[RMT_V];
+#pragma unroll
+    for (int i = 0; i < RMT_V; ++i) carry[i] = real(0);          // nothing upstream of node 0
+    const real cs = m.f1 * m.inv_dz, ct = m.ft * m.inv_dz;       // d f_z / d y_{z-1}
+    for (int base = 0; base < N; base += RMT_BLOCK) {
+        const int node = base + (int)threadIdx.x;
+        const bool valid = node < N;
+        real ai[RMT_V][RMT_V], p[RMT_V], xv[RMT_V], l[RMT_V];
+        unsigned mk = 0u;
+        if (valid) mk = mask[node];
+#pragma unroll
+        for (int r = 0; r < RMT_V; ++r) {
+            real bv = real(0);
+            if (valid) bv = b[(size_t)r * N + node];
+            xv[r] = bv;                                           // reuse xv as b for the moment
+#pragma unroll
+            for (int c = 0; c < RMT_V; ++c) ai[r][c] = valid ? ainv[(size_t)(r * RMT_V + c) * N + node] : real(0);
+            l[r] = ((mk >> r) & 1u) ? ((r < RMT_S) ? cs : ct) : real(0);
+        }
+#pragma unroll
+        for (int r = 0; r < RMT_V; ++r) {
+            real acc = real(0);
+#pragma unroll
+            for (int c = 0; c < RMT_V; ++c) acc += ai[r][c] * xv[c];
+            p[r] = acc;                                           // p = Ainv b
+        }
+        // fold the coupling into the matrix once: ai <- Ainv diag(l)
+#pragma unroll
+        for (int r = 0; r < RMT_V; ++r)
+#pragma unroll
+            for (int c = 0; c < RMT_V; ++c) ai[r][c] *= l[c];
+#pragma unroll
+        for (int r = 0; r < RMT_V; ++r) xv[r] = p[r];
+        real cout[RMT_V];
+        for (int it = 0; it <= sweeps; ++it, ph ^= 1) {           // last pass only publishes the boundary
+            real xup[RMT_V];
+            rmt_shift_up(sh, ph, xv, carry, xup, cout);
+            if (it < sweeps) {
+#pragma unroll
+                for (int r = 0; r < RMT_V; ++r) {
+                    real acc = p[r];
+#pragma unroll
+                    for (int c = 0; c < RMT_V; ++c) acc += ai[r][c] * xup[c];
+                    xv[r] = acc;
+                }
+            }
+        }
+        // ragged last block: the boundary value is not needed any more
+#pragma unroll
+        for (int i = 0; i < RMT_V; ++i) carry[i] = cout[i];
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < RMT_V; ++r) x[(size_t)r * N + node] = xv[r];
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_ros4_mem(
+        real* __restrict__ y, real* __restrict__ work, unsigned* __restrict__ maskbuf,
+        const double* __restrict__ members, const int N, const int E, const double t0,
+        const double t1, const double rtol, const double atol, const double h0,
+        const long long max_steps, double* __restrict__ stats, unsigned* __restrict__ flags) {
+    __shared__ RmtShared sh;
+    rmt_math_init();
+    const int e = blockIdx.x;
+    RmtMember m;
+    rmt_load_member(members + (size_t)e * RMT_NM, m);
+    const size_t per = (size_t)RMT_V * N, tot = per * E;
+    real* ye = y + e * per;
+    real* F = work + 0 * tot + e * per;
+    real* G1 = work + 1 * tot + e * per;
+    real* G2 = work + 2 * tot + e * per;
+    real* G3 = work + 3 * tot + e * per;
+    real* G4 = work + 4 * tot + e * per;
+    real* YS = work + 5 * tot + e * per;
+    real* B = work + 6 * tot + e * per;
+    real* ainv = work + 7 * tot + (size_t)e * RMT_V * RMT_V * N;
+    unsigned* mask = maskbuf + (size_t)e * N;
+    // Kaps-Rentrop / Shampine parameters (gamma = 1/2)
+    const double A21 = 2.0, A31 = 48.0 / 25, A32 = 6.0 / 25, C21 = -8.0, C31 = 372.0 / 25, C32 = 12.0 / 5,
+                 C41 = -112.0 / 125, C42 = -54.0 / 125, C43 = -2.0 / 5, B1 = 19.0 / 9, B2 = 0.5,
+                 B3 = 25.0 / 108, B4 = 125.0 / 108, E1 = 17.0 / 54, E2 = 7.0 / 36, E4 = 125.0 / 108;
+    const double cmax = (double)rmt_max(m.f1, m.ft) * (double)m.inv_dz;
+    const double hcap = 1.0 / (RMT_ROS_GAM * cmax);               // contraction factor <= 1/2
+    rmt_flags_t flag, trial;
+    rmt_flags_clear(flag);
+    unsigned lflag = 0u;
+    int ph = 0, rp = 0;
+    double t = t0, h = fmin(h0, hcap);
+    long long nacc = 0, nrej = 0;
+    while (t < t1 && nacc + nrej < max_steps) {
+        bool last = false;
+        if (t + h >= t1) { h = t1 - t; last = true; }
+        rmt_flags_clear(trial);
+        const real inv_gh = real(1.0 / (RMT_ROS_GAM * h));
+        const double rho = cmax / (1.0 / (RMT_ROS_GAM * h) + cmax);
+        int sweeps = (int)ceil(-27.6 / log(rho)) + 1;             // rho^sweeps <= 1e-12
+        sweeps = sweeps < 2 ? 2 : (sweeps > 60 ? 60 : sweeps);
+        real pivmin = real(__builtin_inf());
+        const real ih = real(1.0 / h);
+        // stage 1
+        rmt_ros_eval<true>(m, sh, ph, ye, F, ainv, mask, N, inv_gh, trial, pivmin);
+        rmt_ros_solve(m, sh, ph, F, G1, ainv, mask, N, sweeps);
+        // stage 2
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    YS[o] = ye[o] + real(A21) * G1[o];
+                }
+            }
+        }
+        rmt_ros_eval<false>(m, sh, ph, YS, F, ainv, mask, N, inv_gh, trial, pivmin);
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    B[o] = F[o] + real(C21) * G1[o] * ih;
+                }
+            }
+        }
+        rmt_ros_solve(m, sh, ph, B, G2, ainv, mask, N, sweeps);
+        // stage 3 (and 4: same RHS)
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    YS[o] = ye[o] + real(A31) * G1[o] + real(A32) * G2[o];
+                }
+            }
+        }
+        rmt_ros_eval<false>(m, sh, ph, YS, F, ainv, mask, N, inv_gh, trial, pivmin);
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    B[o] = F[o] + (real(C31) * G1[o] + real(C32) * G2[o]) * ih;
+                }
+            }
+        }
+        rmt_ros_solve(m, sh, ph, B, G3, ainv, mask, N, sweeps);
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    B[o] = F[o] + (real(C41) * G1[o] + real(C42) * G2[o] + real(C43) * G3[o]) * ih;
+                }
+            }
+        }
+        rmt_ros_solve(m, sh, ph, B, G4, ainv, mask, N, sweeps);
+        // new state (into YS) and error estimate
+        double errloc = 0.0;
+        bool bad = false;
+        for (int base = 0; base < N; base += RMT_BLOCK) {
+            const int node = base + (int)threadIdx.x;
+            if (node < N) {
+#pragma unroll
+                for (int i = 0; i < RMT_V; ++i) {
+                    const size_t o = (size_t)i * N + node;
+                    const double g1 = G1[o], g2 = G2[o], g3 = G3[o], g4 = G4[o], yo = ye[o];
+                    const double yn = yo + B1 * g1 + B2 * g2 + B3 * g3 + B4 * g4;
+                    const double er = E1 * g1 + E2 * g2 + E4 * g4;
+                    YS[o] = real(yn);
+                    bad |= !__builtin_isfinite(yn);
+                    errloc = fmax(errloc, fabs(er) / (atol + rtol * fmax(fabs(yo), fabs(yn))));
+                }
+            }
+        }
+        bad |= !(pivmin > real(0));
+        const double worst = rmt_block_max(sh, rp, (bad || !__builtin_isfinite(errloc)) ? 1.0e300 : errloc);
+        rp ^= 1;
+        double fac;
+        if (worst >= 1.0e300) {
+            fac = 0.25;
+            ++nrej;
+        } else if (worst <= 1.0) {
+            t = last ? t1 : t + h;
+            ++nacc;
+            fac = (worst > 1.89e-4) ? 0.9 * pow(worst, -0.25) : 1.5 * 5.0;     // 4th order: grow <= 7.5x
+            fac = fmin(fac, 5.0);
+            for (int base = 0; base < N; base += RMT_BLOCK) {
+                const int node = base + (int)threadIdx.x;
+                if (node < N) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V; ++i) {
+                        const size_t o = (size_t)i * N + node;
+                        ye[o] = YS[o];
+                    }
+                }
+            }
+            rmt_flags_merge(flag, trial);
+        } else {
+            ++nrej;
+            fac = fmax(0.2, 0.9 * pow(worst, -1.0 / 3.0));
+        }
+        h = fmin(fmax(h * fac, 1e-14), hcap);
+    }
+    if (t < t1) lflag |= RMT_FLAG_STEP;
+    lflag |= rmt_flags_bits(flag);
+    if (threadIdx.x == 0) {
+        stats[(size_t)e * 4 + 0] = t;
+        stats[(size_t)e * 4 + 1] = h;
+        ((long long*)stats)[(size_t)e * 4 + 2] = nacc;
+        ((long long*)stats)[(size_t)e * 4 + 3] = nrej;
+    }
     if (lflag) atomicOr(&flags[e], lflag);
 }
 #endif  // RMT_HOST_EMULATION

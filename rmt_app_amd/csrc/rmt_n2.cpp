@@ -40,7 +40,9 @@ struct rmt_n2_handle {
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
-                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr;
+                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr;
+    unsigned* d_mask = nullptr;
+    size_t mask_elems = 0;
     unsigned long long* d_sync = nullptr;
     double* d_slots = nullptr;
     size_t chain_links = 0;
@@ -157,6 +159,8 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         h->f_multistep = nullptr;
     if (hipModuleGetFunction(&h->f_rk4_chain, h->module, "rmt_n2_rk4_chain") != hipSuccess)
         h->f_rk4_chain = nullptr;
+    if (hipModuleGetFunction(&h->f_ros4, h->module, "rmt_n2_ros4_mem") != hipSuccess)
+        h->f_ros4 = nullptr;
     (void)hipGetLastError();
     CREATE_OK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
@@ -176,6 +180,7 @@ extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (h->d_members) (void)hipFree(h->d_members);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_sync) (void)hipFree(h->d_sync);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -205,8 +210,8 @@ extern "C" int rmt_n2_set_members(rmt_n2_handle* h, const double* members) {
     return 0;
 }
 
-static int ensure_work(rmt_n2_handle* h, size_t arrays) {
-    const size_t need = arrays * (size_t)h->E * h->V * h->N * h->real_size;
+static int ensure_work(rmt_n2_handle* h, size_t arrays, size_t extra_bytes = 0) {
+    const size_t need = arrays * (size_t)h->E * h->V * h->N * h->real_size + extra_bytes;
     if (h->work_bytes >= need) return 0;
     if (h->d_work) {
         HIP_OK(hipStreamSynchronize(h->stream));
@@ -324,6 +329,31 @@ extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, doub
                     (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms,
                     (void*)&stats, (void*)&h->d_flags};
     return launch(h, h->f_rk45_mem, args);
+}
+
+extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, double rtol, double atol,
+                           double h0, int64_t max_steps, rmt_n2_stats* stats) {
+    if (!h || !y || !stats) return fail("null argument");
+    if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad ros4 arguments");
+    if (!h->f_ros4) return fail("code object has no ros4 kernel");
+    if (h->block > 256)
+        return fail("the Rosenbrock kernel holds a VxV matrix per lane: generate the code object with "
+                    "block <= 256 (got %d)", h->block);
+    // 7 vector arrays + the VxV inverse per node (= V more "vector arrays")
+    if (ensure_work(h, 7 + (size_t)h->V)) return 1;
+    const size_t nmask = (size_t)h->E * h->N;
+    if (h->mask_elems < nmask) {
+        if (h->d_mask) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->d_mask)); }
+        h->d_mask = nullptr; h->mask_elems = 0;
+        HIP_OK(hipMalloc((void**)&h->d_mask, nmask * sizeof(unsigned)));
+        h->mask_elems = nmask;
+    }
+    int N = h->N, E = h->E;
+    long long ms = (long long)max_steps;
+    void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_mask, (void*)&h->d_members, (void*)&N,
+                    (void*)&E, (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0,
+                    (void*)&ms, (void*)&stats, (void*)&h->d_flags};
+    return launch(h, h->f_ros4, args);
 }
 
 extern "C" int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host) {

@@ -15,7 +15,7 @@ from . import hipbind, plan
 from .lowering import FLAG_DIV0, FLAG_DOMAIN, FLAG_NONFINITE, FLAG_OVERFLOW, FLAG_STEP
 from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 
-DEVICE_IVPS = ("hip-rk4", "hip-rk45", "AM", "hip-ab3")
+DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "AM", "hip-ab3")
 
 
 def choose_geometry(N, V, fp32=False, E=None):
@@ -143,6 +143,14 @@ class N2Device:
                                                 float(rtol), float(atol), float(h0), int(max_steps),
                                                 C.c_void_p(self._stats.data_ptr())))
 
+    def ros4(self, y, t0, t1, rtol, atol, h0, max_steps):
+        """In place: stiff Rosenbrock(4,3) integration from t0 to t1 with per-reactor step control
+        (needs a code object generated with block <= 256)."""
+        self._chk_state(y)
+        hipbind.check(hipbind.lib().rmt_n2_ros4(self.h, C.c_void_p(y.data_ptr()), float(t0), float(t1),
+                                                float(rtol), float(atol), float(h0), int(max_steps),
+                                                C.c_void_p(self._stats.data_ptr())))
+
     def rk45_stats(self):
         raw = self._stats.cpu().numpy()
         return {"t_end": raw[:, 0].copy(), "h_last": raw[:, 1].copy(),
@@ -245,7 +253,10 @@ def run_n2(modelInput, members_inputs=None):
     inputs = list(members_inputs) if members_inputs else [modelInput]
     named_rows = [plan.member_constants(mi, mech, zNo) for mi in inputs]
     rows = np.array([r for _, r in named_rows])
-    dev = N2Device(mech, rows, zNo, fp32=fp32, block=cfg.get('block'), npt=cfg.get('nodes-per-thread'))
+    block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
+    if ivp == "hip-ros4" and block is None:      # one VxV matrix per lane: at most 256 threads
+        block, npt = min(256, 64*((zNo + 63)//64)), 1
+    dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt)
     try:
         IV = np.array([plan.initial_state(nm, mech, zNo) for nm, _ in named_rows])
         y = dev.to_device(IV)
@@ -269,14 +280,20 @@ def run_n2(modelInput, members_inputs=None):
                 dev.multistep(y, abs(t1 - t0)/n, n, "PreCorr3" if ivp == "AM" else "AdBash3", t0)
                 stats["steps"] += n
                 stats["rhs_evals"] += (2*n + 6) if ivp == "AM" else (n + 8)
+            elif ivp == "hip-ros4":
+                h_next = float(cfg.get('h0', DEVICE_DEFAULTS['ros4-h0'])) if i == 0 else h_next
+                dev.ros4(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['ros4-rtol'])),
+                         float(cfg.get('atol', DEVICE_DEFAULTS['ros4-atol'])), h_next,
+                         int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
             else:
                 dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
                          float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])),
                          float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0'])),
                          int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
             dev.raise_on_flags()
-            if ivp == "hip-rk45":
+            if ivp in ("hip-rk45", "hip-ros4"):
                 st = dev.rk45_stats()
+                h_next = float(np.min(st["h_last"]))
                 stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
                 stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
             Yh = y.cpu().numpy().astype(np.float64)
@@ -284,7 +301,8 @@ def run_n2(modelInput, members_inputs=None):
                 packs[e].append(pack_interval(Yh[e], nm, mech, zNo, t1, modelId))
         if stats["accepted"] is not None:
             stats["steps"] = int(np.sum(stats["accepted"]))
-            stats["rhs_evals"] = int(np.sum(6*(stats["accepted"] + stats["rejected"])) + len(inputs)*tNo)
+            per = 6 if ivp == "hip-rk45" else 3
+            stats["rhs_evals"] = int(np.sum(per*(stats["accepted"] + stats["rejected"])) + len(inputs)*tNo)
         stats["node_steps"] = stats["steps"]*zNo*(len(inputs) if ivp != "hip-rk45" else 1)
     finally:
         dev.close()

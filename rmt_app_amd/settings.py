@@ -27,6 +27,9 @@ DEVICE_DEFAULTS = {
     "rk45-h0": 1e-6,
     "rk45-max-steps": 50_000_000,
     "rk4-dt": 2e-6,
+    "ros4-rtol": 1e-6,
+    "ros4-atol": 1e-9,
+    "ros4-h0": 1e-5,
 }
 
 ROUND_FUN_ACCURACY = 3   # PyREMOT/core/config.py:8-24 ("computation-time" rounding)

@@ -350,3 +350,67 @@ def test_chained_workgroups_agree_with_oracle(N, E, block, npt):
     dev.rk4(y2, 2e-6, 9)
     assert np.max(np.abs(y2.cpu().numpy() - got)) < 1e-12
     dev.close()
+
+
+def test_ros4_vs_oracle_controller():
+    """Stiff Rosenbrock(4,3) with per-reactor step control vs the oracle's restatement (exact
+    bidiagonal solves there, Jacobi sweeps to 1e-12 here): same step history, same end state."""
+    N = 20
+    mi, mech, nm, dev = make_device("dme_script", N, block=64, npt=1)
+    y = dev.to_device(plan.initial_state(nm, mech, N))
+    rtol, atol, h0, t1 = 1e-6, 1e-9, 1e-5, 0.1
+    dev.ros4(y, 0.0, t1, rtol, atol, h0, 10**6)
+    assert not dev.status().any()
+    st = dev.rk45_stats()
+    pr = O.setup_n2(mi, N)
+    want, ost = O.ros4(pr, pr["IV"], 0.0, t1, rtol, atol, h0)
+    assert st["t_end"][0] == t1
+    assert abs(int(st["accepted"][0]) - ost["accepted"]) <= max(3, 0.03*ost["accepted"])
+    got = y.cpu().numpy()[0]
+    scale = np.max(np.abs(want.reshape(7, N)), axis=1, keepdims=True)
+    assert np.max(np.abs(got.reshape(7, N) - want.reshape(7, N))/scale) < 20*rtol
+    dev.close()
+
+
+@pytest.mark.parametrize("name", ["dme_script", "dme_nb"])
+def test_rmtexe_ros4_end_to_end_vs_tight_scipy_reference(name):
+    """rmtExe(ivp='hip-ros4'): a few hundred implicit steps instead of 200 000 explicit ones,
+    outlet mole fractions and temperature <= 1e-6 vs the reference under LSODA rtol 1e-10."""
+    g = np.load(os.path.join(G, "g4_tight_%s_lsoda.npz" % name))
+    mi = INP.ALL_N2_INPUTS[name](ivp="hip-ros4")
+    mi["solver-config"].update({"quiet": True, "rtol": 1e-6, "atol": 1e-9})
+    res = rmtExe(mi)
+    dp = res["resModel"]["dataPack"]
+    worst = 0.0
+    for k in range(5):
+        a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
+        worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
+    assert worst < 1e-6, worst
+    st = res["resModel"]["device-stats"]
+    assert 200 < st["steps"] < 3000, st
+
+
+def test_ros4_1024_nodes_ensemble_matches_explicit():
+    """N = 1024 (4 node blocks per workgroup, Jacobi sweeps across them) on a small sweep:
+    the stiff stepper agrees with RK4 at dt = 2e-6 after 4 ms."""
+    N, E = 1024, 4
+    mech = plan.Mechanism(INP.dme_notebook_input())
+    rows, named = [], []
+    for T in (513, 523, 533, 543):
+        m2 = INP.dme_notebook_input()
+        m2["operating-conditions"]["temperature"] = T
+        nm, row = plan.member_constants(m2, mech, N)
+        rows.append(row), named.append(nm)
+    IV = np.array([plan.initial_state(nm, mech, N) for nm in named])
+    dev = N2Device(mech, np.array(rows), N, block=256, npt=1)
+    y = dev.to_device(IV)
+    dev.ros4(y, 0.0, 4e-3, 1e-7, 1e-10, 1e-6, 10**6)
+    assert not dev.status().any()
+    st = dev.rk45_stats()
+    ref = dev.to_device(IV)
+    dev.rk4(ref, 2e-6, 2000)
+    a, b = y.cpu().numpy().reshape(E, 7, N), ref.cpu().numpy().reshape(E, 7, N)
+    scale = np.max(np.abs(b), axis=2, keepdims=True)
+    assert np.max(np.abs(a - b)/scale) < 2e-6
+    assert np.all(st["accepted"] < 400)
+    dev.close()

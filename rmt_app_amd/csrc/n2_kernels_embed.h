@@ -1402,7 +1402,7 @@ __device__ __forceinline__ void rmt_ros_eval(const RmtMember& m, RmtShared& sh, 
                 real yp[RMT_V], kp[RMT_V];
 #pragma unroll
                 for (int i = 0; i < RMT_V; ++i) yp[i] = ys[0][i];
-                const real d = real(1.5e-8) * rmt_max(rmt_abs(ys[0][c]), real(1e-3));
+                const real d = real(RMT_FP32 ? 3e-4 : 1.5e-8) * rmt_max(rmt_abs(ys[0][c]), real(1e-3));
                 yp[c] += d;
                 const real id = rmt_rcp(yp[c] - ys[0][c]);
                 RmtNode ndp;

@@ -237,11 +237,14 @@ def run_n2(modelInput, members_inputs=None):
     cfg = modelInput['solver-config']
     ivp = cfg['ivp']
     displayResult = cfg['display-result'] == "True"        # KeyError like the reference (:3337)
-    if ivp in ("default", "RK45"):
-        ivp = "hip-rk45"
+    # the reference's "default" is SciPy's LSODA (pbHomoReactor.py:3576); its other stiff choices
+    # are BDF / Radau: all of them map to the device's stiff Rosenbrock stepper; the explicit
+    # SciPy pairs map to the device Dormand-Prince stepper.
+    ivp = {"default": "hip-ros4", "LSODA": "hip-ros4", "BDF": "hip-ros4", "Radau": "hip-ros4",
+           "RK45": "hip-rk45", "RK23": "hip-rk45", "DOP853": "hip-rk45"}.get(ivp, ivp)
     if ivp not in DEVICE_IVPS:
-        raise ValueError("`ivp` must be one of %s (or 'default'); the device build has no "
-                         "implicit/CPU integrators (got %r)" % (DEVICE_IVPS, ivp))
+        raise ValueError("`ivp` must be one of %s, 'default' or a SciPy method name (got %r)"
+                         % (DEVICE_IVPS, ivp))
     zNo = int(cfg.get('zNo', solverSetting['N2']['zNo']))
     tNo = int(cfg.get('tNo', solverSetting['N2']['tNo']))
     fp32 = cfg.get('dtype', 'fp64') in ('fp32', 'float32')

@@ -3,9 +3,9 @@
 result shape ``{"resModel": ..., "comTime": ...}``.
 
 Only the hot path named in BASELINE.json is implemented: ``model == "N2"`` (dynamic homogeneous
-packed-bed reactor).  ``solver-config.ivp`` selects the device integrator: ``"hip-rk4"``,
-``"hip-rk45"``; ``"default"`` maps to ``"hip-rk45"`` (the reference maps it to scipy's LSODA,
-pbHomoReactor.py:3576).  Any other model id raises - the reference silently returns None there
+packed-bed reactor).  ``solver-config.ivp`` selects the device integrator: ``"hip-ros4"`` (stiff
+Rosenbrock), ``"hip-rk4"``, ``"hip-rk45"``, ``"AM"`` (the reference's PreCorr3); ``"default"`` - LSODA
+in the reference, pbHomoReactor.py:3576 - and SciPy's stiff method names map to ``"hip-ros4"``.  Any other model id raises - the reference silently returns None there
 (rmtCore.py:90-127), which is not a behaviour worth mirroring for unsupported models.
 """
 import timeit

@@ -262,11 +262,23 @@ def test_rk45_per_reactor_step_control():
     dev.close()
 
 
-def test_rmtexe_default_ivp_is_device_rk45_and_meets_1e6():
-    """An unmodified modelInput (ivp='default') runs on the device (adaptive RK45) and meets the
-    <= 1e-6 outlet requirement against the reference's tight LSODA run (golden G4)."""
+def test_rmtexe_unmodified_input_runs_on_device_and_meets_1e6():
+    """A completely unmodified modelInput (ivp='default', no extra keys) runs on the device (stiff
+    Rosenbrock, default tolerances) and meets the <= 1e-6 outlet requirement against the
+    reference's tight LSODA run (golden G4)."""
     g = np.load(os.path.join(G, "g4_tight_dme_nb_lsoda.npz"))
     mi = INP.dme_notebook_input()          # ivp == "default"
+    res = rmtExe(mi)
+    dp = res["resModel"]["dataPack"]
+    worst = max(np.max(np.abs(dp[k]["dataYs"][:, -1] - g["dataYs_%d" % k][:, -1])/np.abs(g["dataYs_%d" % k][:, -1]))
+                for k in range(5))
+    assert worst < 1e-6, worst
+
+
+def test_rmtexe_rk45_meets_1e6():
+    """ivp='RK45' (SciPy's name) -> device Dormand-Prince with per-reactor step control."""
+    g = np.load(os.path.join(G, "g4_tight_dme_nb_lsoda.npz"))
+    mi = INP.dme_notebook_input(ivp="RK45")
     mi["solver-config"].update({"quiet": True, "rtol": 1e-8, "atol": 1e-11})
     res = rmtExe(mi)
     dp = res["resModel"]["dataPack"]

@@ -27,6 +27,9 @@
  *                         LSODA, pbHomoReactor.py:3576): linearly-implicit 4th-order Rosenbrock
  *                         (Kaps-Rentrop/Shampine) with embedded error estimate and per-reactor
  *                         step control; SURVEY.md section 8(f) rank 2.
+ *   rmt_n1_profile      - PackedBedHomoReactorClass.runN1 / modelEquationN1 (pbHomoReactor.py:2694-3314):
+ *                         the steady-state model N1, integrated along z* for E reactors at once
+ *                         (one per lane) with the same Rosenbrock scheme; SURVEY.md 8(f) rank 1.
  *   rmt_n2_status       - the exceptions Python raises inside the user lambdas / `raise` at
  *                         pbHomoReactor.py:3614-3626, as per-reactor flag words.
  *
@@ -109,6 +112,10 @@ int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rt
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 int rmt_n2_ros4(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
+/* members1: HOST [E][16+S] rows (layout M1_* in n2_kernels.inc); out: DEVICE double [E][nout][S+2]
+ * (S+1 when iso-thermal) = the state at z* = k/(nout-1); stats: DEVICE [E] */
+int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout, double rtol,
+                   double atol, double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 /* copies the E flag words to host memory (synchronises the stream) and clears them on device */
 int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
 /* which stepper rmt_n2_rk4 uses: 0 = auto (on-chip if N fits one workgroup, else chained

@@ -41,6 +41,8 @@ class HostEmu:
         self.lib.emu_rhs.restype = None
         self.lib.emu_rk4.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_longlong, vp]
         self.lib.emu_rk4.restype = None
+        self.lib.emu_n1_rhs.argtypes = [vp, vp, vp, C.c_int, vp]
+        self.lib.emu_n1_rhs.restype = None
         self.lib.emu_set_threads.argtypes = [C.c_int]
         self.lib.emu_set_threads.restype = C.c_int
 
@@ -55,6 +57,17 @@ class HostEmu:
         out = np.empty_like(y)
         flags = np.zeros(E, dtype=np.uint32)
         self.lib.emu_rhs(y.ctypes.data, out.ctypes.data, members.ctypes.data, N, E, flags.ctypes.data)
+        return out, flags
+
+    def n1_rhs(self, u, members1):
+        """modelEquationN1 of the generated source for E states u (E, S+2)."""
+        u = np.ascontiguousarray(u, dtype=self.dtype)
+        u = u.reshape(-1, u.shape[-1])
+        E = u.shape[0]
+        members1 = np.ascontiguousarray(members1, dtype=np.float64).reshape(E, -1)
+        out = np.empty_like(u)
+        flags = np.zeros(E, dtype=np.uint32)
+        self.lib.emu_n1_rhs(u.ctypes.data, out.ctypes.data, members1.ctypes.data, E, flags.ctypes.data)
         return out, flags
 
     def rk4(self, y, members, N, h, nsteps):

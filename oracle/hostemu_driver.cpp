@@ -66,6 +66,18 @@ extern "C" void emu_rhs(const real* y, real* dydt, const double* members, int N,
     }
 }
 
+extern "C" void emu_n1_rhs(const real* u, real* du, const double* members1, int E, unsigned* flags) {
+    for (int e = 0; e < E; ++e) {
+        real uu[RMT_V1], dd[RMT_V1];
+        for (int i = 0; i < RMT_V1; ++i) uu[i] = u[(size_t)e * RMT_V1 + i];
+        rmt_flags_t f;
+        rmt_flags_clear(f);
+        rmt_n1_rhs(members1 + (size_t)e * RMT_NM1, uu, dd, f);
+        for (int i = 0; i < RMT_V1; ++i) du[(size_t)e * RMT_V1 + i] = dd[i];
+        flags[e] |= rmt_flags_bits(f);
+    }
+}
+
 extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_, long long nsteps,
                         unsigned* flags) {
     const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);

@@ -456,6 +456,80 @@ __device__ __forceinline__ void rmt_node_post(const RmtMember& m, const RmtNode&
 #endif
 }
 
+// ------------------------------------------------------------------ steady-state model N1: node function
+// SURVEY.md section 8(f) rank 1: PackedBedHomoReactorClass.runN1 / modelEquationN1
+// (pbHomoReactor.py:2694-3314), the steady sibling of N2 - an ODE in the dimensionless length z*
+// for u = [c_1..c_S, P*, theta] - integrated by the reference with solve_ivp(LSODA) at
+// t_eval = linspace(0, 1, zNo+1) (:2931).  Along z the chemistry is as stiff as in time, so the
+// same Rosenbrock(4,3) scheme is used, here with a dense (S+2)^2 finite-difference Jacobian and ONE
+// REACTOR PER LANE (an ensemble of N1 profiles); steps are clipped to the output grid.
+//   member row (doubles, host: plan.member_constants_n1): see M1_* below.
+#define RMT_V1 (RMT_S + 1 + (RMT_ISO ? 0 : 1))
+#define RMT_NM1 (16 + RMT_S)
+#define M1_CMAX 0
+#define M1_TF 1
+#define M1_PF 2          // = P0
+#define M1_SPCO0 3
+#define M1_ERGA 4        // 150 mu ergB/dp^2 * zf/Pf      (times SuGaVe)
+#define M1_ERGC 5        // 1.75 ergD/dp * zf/Pf          (times rho SuGaVe^2)
+#define M1_SUGAVE0 6
+#define M1_RHO_K 7       // 1/(R GaDe0)
+#define M1_INV_CP0 8
+#define M1_EPS 9
+#define M1_INV_MACOTE 10
+#define M1_INV_HECOTE 11
+#define M1_UA 12
+#define M1_TM 13
+#define M1_GADE0 14
+#define M1_CIN 16
+
+__device__ __forceinline__ void rmt_n1_rhs(const double* __restrict__ mr, const real (&u)[RMT_V1],
+                                           real (&du)[RMT_V1], rmt_flags_t& flag) {
+    const real cmax = real(mr[M1_CMAX]), tf = real(mr[M1_TF]), pf = real(mr[M1_PF]);
+    real C[RMT_S], x[RMT_S];
+    real ctot = real(0);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) { C[i] = u[i] * cmax; ctot += C[i]; }      // :3123 (no clamp in N1)
+    const real inv_ctot = rmt_rcp(ctot);
+    real mw = real(0);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) { x[i] = C[i] * inv_ctot; mw += x[i] * RMT_MW[i]; }
+    const real M = mw * real(1e-3);
+    const real P = u[RMT_S] * pf;                                              // :3135
+#if RMT_ISO
+    const real T = tf;
+#else
+    const real T = u[RMT_S + 1] * tf + tf;
+#endif
+    // interstitial velocity from the EOS (rmtUtility.py:404-421): InGaVe* = (Ctot/SpCo0)(P0/P)
+    const real vstar = rmt_div(ctot * pf, real(mr[M1_SPCO0]) * P);
+    const real su = vstar * real(mr[M1_SUGAVE0]);
+    const real rho = rmt_div(P * M, real(8.314472) * T);                        // rmtThermo.py:353
+    const real rho_s = rho * rmt_rcp(real(mr[M1_GADE0]));
+    du[RMT_S] = -(real(mr[M1_ERGA]) * su + real(mr[M1_ERGC]) * rho * su * su);  // :3206-3220
+    real r[RMT_R];
+    rmt_kinetics(T, P, x, C, r, flag);
+    real src[RMT_S];
+    rmt_species_source(r, src);
+    const real iv = rmt_rcp(vstar);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) du[i] = iv * src[i] * real(mr[M1_INV_MACOTE]);   // :3283-3289
+#if !RMT_ISO
+    real cpbar[RMT_S], cpm = real(0);
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) { cpbar[i] = rmt_cp_mean(i, T); cpm += x[i] * cpbar[i]; }
+    real dcp[RMT_R];
+    rmt_reaction_dcp(cpbar, dcp);
+    real qr = real(0);
+#pragma unroll
+    for (int q = 0; q < RMT_R; ++q) qr += r[q] * (dcp[q] * (T - RMT_TREF) + RMT_DH25[q]);
+    const real tm = real(mr[M1_TM]);
+    const real qm = (tm == real(0)) ? real(0) : real(mr[M1_UA]) * (tm - T);
+    const real cp_eff = cpm * real(mr[M1_INV_CP0]) * real(mr[M1_EPS]);
+    du[RMT_S + 1] = rmt_div((qm - qr) * real(mr[M1_INV_HECOTE]), rho_s * cp_eff * vstar);   // :3284,3298
+#endif
+}
+
 #ifndef RMT_HOST_EMULATION
 // ------------------------------------------------------------------ affine maps P -> a*P + b
 struct RmtAff { preal a, b; };
@@ -1654,6 +1728,158 @@ extern "C" __global__ __launch_bounds__(RMT_BLOCK) void rmt_n2_ros4_mem(
         ((long long*)stats)[(size_t)e * 4 + 3] = nrej;
     }
     if (lflag) atomicOr(&flags[e], lflag);
+}
+
+// ===================================================================== kernel: steady-state model N1 (batched)
+// (node function rmt_n1_rhs and the M1_* row layout: see the node-physics section above)
+template <int NV>
+__device__ __forceinline__ real rmt_invert_n(real (&a)[NV][NV]) {
+    real pmin = real(__builtin_inf());
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        pmin = rmt_min(pmin, rmt_abs(a[p][p]));
+        const real ip = rmt_rcp(a[p][p]);
+        a[p][p] = real(1);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) a[p][c] *= ip;
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            if (r != p) {
+                const real f = a[r][p];
+                a[r][p] = real(0);
+#pragma unroll
+                for (int c = 0; c < NV; ++c) a[r][c] -= f * a[p][c];
+            }
+        }
+    }
+    return pmin;
+}
+
+extern "C" __global__ __launch_bounds__(64) void rmt_n1_ros4(
+        const double* __restrict__ members1, double* __restrict__ out /* [E][nout][V1] */,
+        const int E, const int nout, const double rtol, const double atol, const double h0,
+        const long long max_steps, double* __restrict__ stats, unsigned* __restrict__ flags) {
+    rmt_math_init();
+    const int e = blockIdx.x * 64 + (int)threadIdx.x;
+    const bool live = e < E;
+    const double* mr = members1 + (size_t)(live ? e : 0) * RMT_NM1;
+    const double A21 = 2.0, A31 = 48.0 / 25, A32 = 6.0 / 25, C21 = -8.0, C31 = 372.0 / 25, C32 = 12.0 / 5,
+                 C41 = -112.0 / 125, C42 = -54.0 / 125, C43 = -2.0 / 5, B1 = 19.0 / 9, B2 = 0.5,
+                 B3 = 25.0 / 108, B4 = 125.0 / 108, E1 = 17.0 / 54, E2 = 7.0 / 36, E4 = 125.0 / 108;
+    real u[RMT_V1];
+#pragma unroll
+    for (int i = 0; i < RMT_S; ++i) u[i] = real(mr[M1_CIN + i]);              // :2831-2839
+    u[RMT_S] = real(1);
+#if !RMT_ISO
+    u[RMT_S + 1] = real(0);
+#endif
+    rmt_flags_t flag, trial;
+    rmt_flags_clear(flag);
+    double z = 0.0, h = h0;
+    long long nacc = 0, nrej = 0;
+    int kout = 0;
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < RMT_V1; ++i) out[((size_t)e * nout + 0) * RMT_V1 + i] = (double)u[i];
+    }
+    kout = 1;
+    bool active = live;
+    // every lane runs its own step sequence; the loop ends when no lane of the wave is active
+    while (__any(active)) {
+        if (active) {
+            const double zt = (double)kout / (double)(nout - 1);
+            bool hit = false;
+            double hs = h;
+            if (z + hs >= zt) { hs = zt - z; hit = true; }
+            rmt_flags_clear(trial);
+            real f1[RMT_V1], a[RMT_V1][RMT_V1];
+            rmt_n1_rhs(mr, u, f1, trial);
+#pragma unroll
+            for (int c = 0; c < RMT_V1; ++c) {
+                real up[RMT_V1], fp[RMT_V1];
+#pragma unroll
+                for (int i = 0; i < RMT_V1; ++i) up[i] = u[i];
+                const real d = real(RMT_FP32 ? 3e-4 : 1.5e-8) * rmt_max(rmt_abs(u[c]), real(1e-3));
+                up[c] += d;
+                const real id = rmt_rcp(up[c] - u[c]);
+                rmt_flags_t sf;
+                rmt_flags_clear(sf);
+                rmt_n1_rhs(mr, up, fp, sf);
+#pragma unroll
+                for (int r = 0; r < RMT_V1; ++r) a[r][c] = -(fp[r] - f1[r]) * id;
+            }
+            const real inv_gh = real(1.0 / (RMT_ROS_GAM * hs)), ih = real(1.0 / hs);
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i) a[i][i] += inv_gh;
+            const real pv = rmt_invert_n<RMT_V1>(a);
+            real g1[RMT_V1], g2[RMT_V1], g3[RMT_V1], g4[RMT_V1], b[RMT_V1], us[RMT_V1], f3[RMT_V1];
+#define RMT_MATVEC(dst, src)                                                        \
+            _Pragma("unroll") for (int r_ = 0; r_ < RMT_V1; ++r_) {                 \
+                real acc_ = real(0);                                                \
+                _Pragma("unroll") for (int c_ = 0; c_ < RMT_V1; ++c_) acc_ += a[r_][c_] * src[c_]; \
+                dst[r_] = acc_;                                                     \
+            }
+            RMT_MATVEC(g1, f1)
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i) us[i] = u[i] + real(A21) * g1[i];
+            rmt_n1_rhs(mr, us, f3, trial);
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i) b[i] = f3[i] + real(C21) * g1[i] * ih;
+            RMT_MATVEC(g2, b)
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i) us[i] = u[i] + real(A31) * g1[i] + real(A32) * g2[i];
+            rmt_n1_rhs(mr, us, f3, trial);
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i) b[i] = f3[i] + (real(C31) * g1[i] + real(C32) * g2[i]) * ih;
+            RMT_MATVEC(g3, b)
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i)
+                b[i] = f3[i] + (real(C41) * g1[i] + real(C42) * g2[i] + real(C43) * g3[i]) * ih;
+            RMT_MATVEC(g4, b)
+#undef RMT_MATVEC
+            double worst = 0.0;
+            bool bad = !(pv > real(0));
+            real un[RMT_V1];
+#pragma unroll
+            for (int i = 0; i < RMT_V1; ++i) {
+                const double yn = (double)u[i] + B1 * (double)g1[i] + B2 * (double)g2[i] + B3 * (double)g3[i] + B4 * (double)g4[i];
+                const double er = E1 * (double)g1[i] + E2 * (double)g2[i] + E4 * (double)g4[i];
+                un[i] = real(yn);
+                bad |= !__builtin_isfinite(yn);
+                worst = fmax(worst, fabs(er) / (atol + rtol * fmax(fabs((double)u[i]), fabs(yn))));
+            }
+            if (bad || !__builtin_isfinite(worst)) {
+                h = fmax(hs * 0.25, 1e-14);
+                ++nrej;
+            } else if (worst <= 1.0) {
+                z = hit ? zt : z + hs;
+                ++nacc;
+#pragma unroll
+                for (int i = 0; i < RMT_V1; ++i) u[i] = un[i];
+                rmt_flags_merge(flag, trial);
+                const double fac = fmin((worst > 1.89e-4) ? 0.9 * pow(worst, -0.25) : 7.5, 5.0);
+                h = (hit ? h : hs) * fac;                       // a clipped step does not shrink h
+                if (hit) {
+#pragma unroll
+                    for (int i = 0; i < RMT_V1; ++i) out[((size_t)e * nout + kout) * RMT_V1 + i] = (double)u[i];
+                    ++kout;
+                }
+            } else {
+                ++nrej;
+                h = fmax(hs * fmax(0.2, 0.9 * pow(worst, -1.0 / 3.0)), 1e-14);
+            }
+            if (kout >= nout || nacc + nrej >= max_steps) active = false;
+        }
+    }
+    if (live) {
+        unsigned lf = rmt_flags_bits(flag);
+        if (kout < nout) lf |= RMT_FLAG_STEP;
+        stats[(size_t)e * 4 + 0] = z;
+        stats[(size_t)e * 4 + 1] = h;
+        ((long long*)stats)[(size_t)e * 4 + 2] = nacc;
+        ((long long*)stats)[(size_t)e * 4 + 3] = nrej;
+        if (lf) atomicOr(&flags[e], lf);
+    }
 }
 #endif  // RMT_HOST_EMULATION
 )RMTSRC"

@@ -40,7 +40,8 @@ struct rmt_n2_handle {
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
-                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr;
+                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr, f_n1 = nullptr;
+    double* d_members1 = nullptr;
     unsigned* d_mask = nullptr;
     size_t mask_elems = 0;
     unsigned long long* d_sync = nullptr;
@@ -161,6 +162,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         h->f_rk4_chain = nullptr;
     if (hipModuleGetFunction(&h->f_ros4, h->module, "rmt_n2_ros4_mem") != hipSuccess)
         h->f_ros4 = nullptr;
+    if (hipModuleGetFunction(&h->f_n1, h->module, "rmt_n1_ros4") != hipSuccess) h->f_n1 = nullptr;
     (void)hipGetLastError();
     CREATE_OK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
@@ -181,6 +183,7 @@ extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_work) (void)hipFree(h->d_work);
     if (h->d_mask) (void)hipFree(h->d_mask);
+    if (h->d_members1) (void)hipFree(h->d_members1);
     if (h->d_sync) (void)hipFree(h->d_sync);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -354,6 +357,26 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
                     (void*)&E, (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0,
                     (void*)&ms, (void*)&stats, (void*)&h->d_flags};
     return launch(h, h->f_ros4, args);
+}
+
+extern "C" int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout, double rtol,
+                              double atol, double h0, int64_t max_steps, rmt_n2_stats* stats) {
+    if (!h || !members1 || !out || !stats) return fail("null argument");
+    if (nout < 2 || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad N1 arguments");
+    if (!h->f_n1) return fail("code object has no N1 kernel");
+    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
+    if (!h->d_members1) HIP_OK(hipMalloc((void**)&h->d_members1, mbytes));
+    HIP_OK(hipMemcpyAsync(h->d_members1, members1, mbytes, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    int E = h->E;
+    long long ms = (long long)max_steps;
+    void* args[] = {(void*)&h->d_members1, (void*)&out, (void*)&E, (void*)&nout, (void*)&rtol, (void*)&atol,
+                    (void*)&h0, (void*)&ms, (void*)&stats, (void*)&h->d_flags};
+    HIP_OK(hipEventRecord(h->ev0, h->stream));
+    HIP_OK(hipModuleLaunchKernel(h->f_n1, (unsigned)((E + 63) / 64), 1, 1, 64, 1, 1, 0, h->stream, args, nullptr));
+    HIP_OK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return 0;
 }
 
 extern "C" int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host) {

@@ -62,6 +62,7 @@ def lib():
     L.rmt_n2_multistep.argtypes = [vp, vp, dbl, dbl, i64, C.c_int]
     L.rmt_n2_rk45.argtypes = [vp, vp, dbl, dbl, dbl, dbl, dbl, i64, vp]
     L.rmt_n2_ros4.argtypes = [vp, vp, dbl, dbl, dbl, dbl, dbl, i64, vp]
+    L.rmt_n1_profile.argtypes = [vp, C.POINTER(dbl), vp, C.c_int, dbl, dbl, dbl, i64, vp]
     L.rmt_n2_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rmt_n2_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     if L.rmt_n2_abi_version() != ABI_VERSION:

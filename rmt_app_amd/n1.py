@@ -1,0 +1,79 @@
+"""Steady-state model N1 on the device: the replacement for PackedBedHomoReactorClass.runN1
+(PyREMOT/docs/pbHomoReactor.py:2694-3015).  The reference integrates the S+2 unknowns
+[c_i, P*, theta] along the dimensionless length with solve_ivp(LSODA) and samples
+t_eval = linspace(0, 1, zNo+1) (:2931); here one launch integrates every member of an ensemble
+(one reactor per lane) with the Rosenbrock(4,3) scheme of the N2 stiff stepper."""
+import ctypes as C
+from timeit import default_timer as timer
+
+import numpy as np
+
+from . import hipbind, plan
+from .n2 import N2Device
+from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
+
+
+def pack_profile(U, named, mech, modelId, elapsed):
+    """dataPack entry of runN1 (pbHomoReactor.py:2947-3008; sortResult4, solResultAnalysis.py:191-249).
+    U: (nout, S+2) dimensionless states."""
+    S = mech.S
+    Y = np.asarray(U, dtype=np.float64).T                     # (S+2, nout) like sol.y
+    nout = Y.shape[1]
+    conc_dl = Y[0:S, :]
+    temp_dl = Y[S + 1, :] if not mech.iso else np.repeat(0, nout).reshape(nout)
+    conc = conc_dl*named["Cmax"]
+    Preal = (Y[S]*named["Pf"]).reshape((1, nout))
+    mofr = conc/np.sum(conc, axis=0)
+    labelList = list(mech.compList) + ["Pressure"]
+    parts = [mofr, Preal]
+    Treal = None
+    if not mech.iso:
+        labelList.append("Temperature")
+        Treal = (Y[S + 1]*named["Tf"] + named["Tf"]).reshape((1, nout))
+        parts.append(Treal)
+    dataXs = np.linspace(0, 1, nout)
+    return {
+        "modelId": modelId, "processType": mech.processType, "successStatus": True,
+        "computation-time": elapsed, "dataShape": np.array(dataXs).shape, "labelList": labelList,
+        "indexList": [S, S, S + 1], "dataTime": [], "dataXs": dataXs,
+        "dataYCons1": conc_dl, "dataYCons2": conc, "dataYTemp1": temp_dl,
+        "dataYTemp2": Treal if Treal is not None else np.zeros((1, nout)),
+        "dataYs": np.concatenate(parts, axis=0),
+    }
+
+
+def run_n1(modelInput, members_inputs=None):
+    """runN1 on the device; returns the reference's list with one dataPack dict (or, for an
+    ensemble, a list with one dict per member)."""
+    start = timer()
+    cfg = modelInput['solver-config']
+    displayResult = cfg['display-result'] == "True"
+    zNo = int(cfg.get('zNo', solverSetting['N1']['zNo']))
+    nout = zNo + 1
+    mech = plan.Mechanism(modelInput)
+    inputs = list(members_inputs) if members_inputs else [modelInput]
+    pairs = [plan.member_constants_n1(mi, mech) for mi in inputs]
+    rows1 = np.ascontiguousarray(np.array([r for _, r in pairs]))
+    # the handle is an N2 handle (same generated module); its N2 member rows are not used here
+    dummy = np.array([plan.member_constants(mi, mech, 64)[1] for mi in inputs])
+    dev = N2Device(mech, dummy, 64, block=64, npt=1, specialize=False)
+    try:
+        torch = dev.torch
+        V1 = mech.S + (1 if mech.iso else 2)
+        out = torch.zeros((len(inputs), nout, V1), dtype=torch.float64, device=dev.device)
+        hipbind.check(hipbind.lib().rmt_n1_profile(
+            dev.h, rows1.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(out.data_ptr()), nout,
+            float(cfg.get('rtol', DEVICE_DEFAULTS['n1-rtol'])), float(cfg.get('atol', DEVICE_DEFAULTS['n1-atol'])),
+            float(cfg.get('h0', 1e-6)), int(cfg.get('max-steps', 10**7)), C.c_void_p(dev._stats.data_ptr())))
+        dev.raise_on_flags()
+        stats = dev.rk45_stats()
+        U = out.cpu().numpy()
+    finally:
+        dev.close()
+    elapsed = np.round(timer() - start, ROUND_FUN_ACCURACY)
+    packs = [pack_profile(U[e], pairs[e][0], mech, modelInput['model'], elapsed) for e in range(len(inputs))]
+    for p, acc, rej in zip(packs, stats["accepted"], stats["rejected"]):
+        p["device-stats"] = {"accepted": int(acc), "rejected": int(rej)}
+    if displayResult:
+        print("display-result: plotting of steady-state profiles is outside the device path")
+    return packs if members_inputs else [packs[0]]

@@ -281,6 +281,45 @@ def member_constants(modelInput, mech, zNo):
     return named, row
 
 
+MEMBER1_FIELDS = {
+    "CMAX": 0, "TF": 1, "PF": 2, "SPCO0": 3, "ERGA": 4, "ERGC": 5, "SUGAVE0": 6, "RHO_K": 7,
+    "INV_CP0": 8, "EPS": 9, "INV_MACOTE": 10, "INV_HECOTE": 11, "UA": 12, "TM": 13, "GADE0": 14, "CIN": 16,
+}
+
+
+def member_constants_n1(modelInput, mech):
+    """Packed constants of the steady-state model N1: the setup block of runN1
+    (pbHomoReactor.py:2694-2900) - identical to runN2's apart from vf = VoFlRa0/CrSeAr - and the
+    h-independent factors of modelEquationN1 (:3017-3314); layout M1_* in csrc/n2_kernels.inc."""
+    nm, _ = member_constants(modelInput, mech, 2)
+    mi = modelInput
+    ReSpec = mi['reactor']
+    PaDi, BeVoFr = ReSpec['PaDi'], ReSpec['BeVoFr']
+    vf = nm["VoFlRa0"]/nm["CrSeAr"]                                     # :2763
+    zf, Pf = nm["zf"], nm["Pf"]
+    GaMaCoTe0 = (vf/zf)*nm["Cmax"]
+    GaHeCoTe0 = (nm["GaDe0"]*vf*nm["Tf"]*(nm["Cpf"]/nm["MiMoWe0"])/zf)
+    ergB = ((1 - BeVoFr)**2)/(BeVoFr**3)
+    ergD = (1 - BeVoFr)/(BeVoFr**3)
+    row = np.zeros(MEMBER_FIXED + mech.S)
+    F = MEMBER1_FIELDS
+    row[F["CMAX"]], row[F["TF"]], row[F["PF"]], row[F["SPCO0"]] = nm["Cmax"], nm["Tf"], Pf, nm["SpCo0"]
+    row[F["ERGA"]] = 150*nm["GaMiVi"]*ergB/(PaDi**2)/(Pf/zf)             # :3206-3220
+    row[F["ERGC"]] = 1.75*ergD/PaDi/(Pf/zf)
+    row[F["SUGAVE0"]] = (nm["VoFlRa0"]/(nm["CrSeAr"]*BeVoFr))*BeVoFr    # InGaVe0*eps, :3100-3102
+    row[F["RHO_K"]] = 1.0/(R_CONST*nm["GaDe0"])
+    row[F["INV_CP0"]] = 1.0/nm["GaCpMeanMix0"]
+    row[F["EPS"]] = BeVoFr
+    row[F["INV_MACOTE"]] = 1.0/GaMaCoTe0
+    row[F["INV_HECOTE"]] = 1.0/GaHeCoTe0
+    row[F["UA"]] = nm["U"]*nm["EfHeTrAr"]
+    row[F["TM"]] = nm["Tm"]
+    row[F["GADE0"]] = nm["GaDe0"]
+    row[F["CIN"]:F["CIN"] + mech.S] = nm["SpCoi0"]/nm["Cmax"]
+    nm = dict(nm, vf=vf)
+    return nm, row
+
+
 def uniform_columns(rows):
     """(first row, bool mask of the columns that hold one value in every row)."""
     rows = np.asarray(rows, dtype=float)

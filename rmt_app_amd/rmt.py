@@ -31,10 +31,17 @@ def rmtExe(modelInput):
                 from .ensemble import expand_members
                 ensemble = expand_members(modelInput, ensemble)
             resModel = run_n2(modelInput, ensemble)
+        elif modelType == "N1":
+            from .n1 import run_n1
+            ensemble = modelInput['solver-config'].get('ensemble')
+            if ensemble is not None:
+                from .ensemble import expand_members
+                ensemble = expand_members(modelInput, ensemble)
+            resModel = run_n1(modelInput, ensemble)
         else:
             raise NotImplementedError(
-                "model %r is outside the MI355X hot path (only 'N2' is built; SURVEY.md section 8)"
-                % (modelType,))
+                "model %r is outside the MI355X hot path (only 'N2' and its steady sibling 'N1' are "
+                "built; SURVEY.md section 8)" % (modelType,))
         tac = timeit.default_timer()
         # the reference's comTime is (timeit.timeit()-timeit.timeit())*1000, i.e. noise
         # (rmt.py:28,67,70); here it is the real wall time in ms.

@@ -30,6 +30,8 @@ DEVICE_DEFAULTS = {
     "ros4-rtol": 1e-6,
     "ros4-atol": 1e-9,
     "ros4-h0": 1e-5,
+    "n1-rtol": 1e-8,     # the steady profile is one lane's worth of work: afford tight defaults
+    "n1-atol": 1e-11,
 }
 
 ROUND_FUN_ACCURACY = 3   # PyREMOT/core/config.py:8-24 ("computation-time" rounding)

@@ -426,3 +426,65 @@ def test_ros4_1024_nodes_ensemble_matches_explicit():
     assert np.max(np.abs(a - b)/scale) < 2e-6
     assert np.all(st["accepted"] < 400)
     dev.close()
+
+
+def test_rmtexe_ensemble_sweep_api():
+    """solver-config.ensemble = {"temperature": [...], "pressure": [...]}: one launch per output
+    interval for the whole sweep; every member equals its own single-reactor rmtExe run."""
+    base = INP.dme_notebook_input(ivp="hip-rk4", period=0.004)
+    base["solver-config"].update({"quiet": True, "dt": 2e-6, "zNo": 64, "tNo": 2,
+                                  "ensemble": {"temperature": [513.0, 533.0], "pressure": [4.0e6, 5.0e6, 6.0e6]}})
+    res = rmtExe(base)
+    ens = res["resModel"]["ensemble"]
+    assert len(ens) == 6 and len(ens[0]["dataPack"]) == 2
+    from rmt_app_amd.ensemble import expand_members
+    members = expand_members(base, base["solver-config"]["ensemble"])
+    for e in (0, 4):
+        single = dict(members[e])
+        single["solver-config"] = {k: v for k, v in base["solver-config"].items() if k != "ensemble"}
+        one = rmtExe(single)["resModel"]["dataPack"]
+        for k in range(2):
+            np.testing.assert_allclose(ens[e]["dataPack"][k]["dataYs"], one[k]["dataYs"], rtol=1e-12)
+    # the members really differ
+    assert abs(ens[0]["dataPack"][1]["dataYs"][6, -1] - ens[5]["dataPack"][1]["dataYs"][6, -1]) > 1.0
+
+
+def test_rmtexe_n1_steady_state_profile():
+    """BASELINE configs[0] (README steady-state example, model N1) on the device: the profile along
+    z* against the oracle's modelEquationN1 under LSODA rtol 1e-11 (<= 1e-6 everywhere) and against
+    the reference's own default-tolerance run (golden G6; that run is only ~1e-4 accurate)."""
+    from scipy.integrate import solve_ivp
+    g = np.load(os.path.join(G, "g6_n1.npz"))
+    mi = INP.n1_notebook_input()
+    res = rmtExe(mi)
+    d = res["resModel"][0]
+    assert d["dataYs"].shape == g["dataYs"].shape == (8, 101)
+    assert d["labelList"] == INP.DME_COMPONENTS + ["Pressure", "Temperature"] and d["indexList"] == [6, 6, 7]
+    pr = O.setup_n1(mi)
+    tight = solve_ivp(lambda t, y: O.n1_rhs(t, y, pr), [0, 1], pr["IV"], method="LSODA", rtol=1e-11,
+                      atol=1e-13, t_eval=np.linspace(0, 1, 101))
+    S = 6
+    conc = tight.y[:S]*np.max(pr["SpCoi0"])
+    want = np.concatenate([conc/conc.sum(0), (tight.y[S]*pr["Pf"]).reshape(1, -1),
+                           (tight.y[S + 1]*pr["Tf"] + pr["Tf"]).reshape(1, -1)])
+    assert np.max(np.abs(d["dataYs"] - want)/np.abs(want)) < 1e-6
+    assert np.max(np.abs(d["dataYs"] - g["dataYs"])/np.abs(g["dataYs"])) < 5e-3
+    for key in ("dataYCons1", "dataYCons2", "dataYTemp1", "dataYTemp2", "dataXs"):
+        assert np.shape(d[key]) == g[key].shape, key
+    # BASELINE.md outlet of the reference run: T = 620.857 K, P = 4.99266 MPa
+    assert abs(d["dataYs"][7, -1] - 620.857) < 0.05 and abs(d["dataYs"][6, -1] - 4992663.0) < 50.0
+
+
+def test_n1_ensemble_one_reactor_per_lane():
+    mi = INP.n1_notebook_input()
+    mi["solver-config"]["ensemble"] = {"temperature": list(np.linspace(503.0, 543.0, 70)), "pressure": [5.0e6]}
+    packs = rmtExe(mi)["resModel"]
+    assert len(packs) == 70
+    Tout = np.array([p["dataYs"][7, -1] for p in packs])
+    assert np.all(np.isfinite(Tout)) and np.all(np.diff(Tout) > 0)       # hotter feed -> hotter outlet
+    one = INP.n1_notebook_input()
+    one["operating-conditions"]["temperature"] = float(np.linspace(503.0, 543.0, 70)[33])
+    c0 = np.array(INP.n1_notebook_input()["feed"]["concentration"])
+    one["feed"]["concentration"] = (c0/c0.sum())*5.0e6/(INP.R_CONST*one["operating-conditions"]["temperature"])
+    single = rmtExe(one)["resModel"][0]
+    np.testing.assert_allclose(packs[33]["dataYs"], single["dataYs"], rtol=1e-9)

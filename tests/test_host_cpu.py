@@ -303,3 +303,23 @@ def test_generated_node_physics_near_steady_states(template):
     for k in range(len(Y)):
         ok, d = backward_ok(out[k], F[k], fv, Y[k], 7)
         assert ok, (k, d)
+
+
+def test_generated_n1_node_function_vs_reference(template):
+    """Steady-state sibling N1: the generated rmt_n1_rhs (host build) against the reference's
+    modelEquationN1 outputs captured in golden G6, and the N1 member row against the oracle setup."""
+    g = np.load(os.path.join(G, "g6_n1.npz"))
+    mi = INP.n1_notebook_input()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants_n1(mi, mech)
+    pr = O.setup_n1(mi)
+    assert relerr(1.0/row[plan.MEMBER1_FIELDS["INV_HECOTE"]], pr["GaHeCoTe0"]) < 1e-14
+    assert relerr(1.0/row[plan.MEMBER1_FIELDS["INV_MACOTE"]], pr["GaMaCoTe0"][0]) < 1e-14
+    emu = HostEmu(mech.source(template), tag="dme_n1")
+    Y, F = g["rhs_y"], g["rhs_f"]
+    out, flags = emu.n1_rhs(Y, np.tile(row, (len(Y), 1)))
+    assert not flags.any()
+    for k in range(len(Y)):
+        # k = 2 is the outlet state, close to chemical equilibrium: the rates are differences of
+        # nearly equal forward/backward terms there (same conditioning issue as tests/parity.py)
+        assert relerr(out[k], F[k]) < (1e-11 if k < 2 else 1e-7), (k, out[k], F[k])

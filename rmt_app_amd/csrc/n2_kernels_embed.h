@@ -531,6 +531,32 @@ __device__ __forceinline__ void rmt_n1_rhs(const double* __restrict__ mr, const 
 }
 
 #ifndef RMT_HOST_EMULATION
+// ---- cross-lane moves on the DPP path (no LDS crossbar round trip) ----------------------------
+// RMT_DPP 1: v_mov_b32 ... row_shr / row_bcast / wave_shr (gfx9 DPP controls) for the 64-lane
+// scan and the lane-1 neighbour fetch; RMT_DPP 0: __shfl_up (ds_bpermute_b32).
+#ifndef RMT_DPP
+#define RMT_DPP 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double rmt_dpp(const double old, const double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float rmt_dpp(const float old, const float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// value of lane-1 (lane 0 keeps its own value, like __shfl_up(v, 1))
+template <typename T>
+__device__ __forceinline__ T rmt_lane_up1(const T v) {
+#if RMT_DPP
+    return rmt_dpp<0x138, 0xf>(v, v);                 // wave_shr:1
+#else
+    return __shfl_up(v, 1);
+#endif
+}
+
 // ------------------------------------------------------------------ affine maps P -> a*P + b
 struct RmtAff { preal a, b; };
 __device__ __forceinline__ RmtAff rmt_then(const RmtAff first, const RmtAff second) {
@@ -629,8 +655,26 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
         loc[j].b = (j < nvalid) ? m.beta : preal(0);
         mine = rmt_then(mine, loc[j]);
     }
-    // inclusive Kogge-Stone scan of the per-lane maps over the wave
+    // inclusive scan of the per-lane maps over the wave
     RmtAff inc = mine;
+#if RMT_DPP
+    {   // lanes whose source is out of range / masked receive the identity map (a = 1, b = 0)
+#define RMT_SCAN_STEP(CTRL, MASK)                                               \
+        {                                                                       \
+            RmtAff prev;                                                        \
+            prev.a = rmt_dpp<CTRL, MASK>(preal(1), inc.a);                      \
+            prev.b = rmt_dpp<CTRL, MASK>(preal(0), inc.b);                      \
+            inc = rmt_then(prev, inc);                                          \
+        }
+        RMT_SCAN_STEP(0x111, 0xf)      // row_shr:1
+        RMT_SCAN_STEP(0x112, 0xf)      // row_shr:2
+        RMT_SCAN_STEP(0x114, 0xf)      // row_shr:4
+        RMT_SCAN_STEP(0x118, 0xf)      // row_shr:8
+        RMT_SCAN_STEP(0x142, 0xa)      // row_bcast:15 -> rows 1, 3
+        RMT_SCAN_STEP(0x143, 0xc)      // row_bcast:31 -> rows 2, 3
+#undef RMT_SCAN_STEP
+    }
+#else
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         RmtAff prev;
@@ -638,6 +682,7 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
         prev.b = __shfl_up(inc.b, d);
         if (lane >= d) inc = rmt_then(prev, inc);
     }
+#endif
     // clamped state of my last node, for my downstream neighbour
     real last[RMT_V];
 #pragma unroll
@@ -652,12 +697,12 @@ __device__ __forceinline__ void rmt_rhs_block(const RmtMember& m, RmtShared& sh,
         for (int i = 0; i < RMT_V; ++i) sh.bnd[buf][wave][i] = last[i];
     }
     RmtAff exc;
-    exc.a = __shfl_up(inc.a, 1);
-    exc.b = __shfl_up(inc.b, 1);
+    exc.a = rmt_lane_up1(inc.a);
+    exc.b = rmt_lane_up1(inc.b);
     if (lane == 0) { exc.a = preal(1); exc.b = preal(0); }
     real up[RMT_V];
 #pragma unroll
-    for (int i = 0; i < RMT_V; ++i) up[i] = __shfl_up(last[i], 1);
+    for (int i = 0; i < RMT_V; ++i) up[i] = rmt_lane_up1(last[i]);
     if (CHAIN) {
         if (wave == 0) {                          // all waiting is done by one wave, before the barrier
             int st = 0;
@@ -1405,7 +1450,7 @@ __device__ __forceinline__ void rmt_shift_up(RmtShared& sh, const int buf, const
                                              real (&carry_out)[RMT_V]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < RMT_V; ++i) xup[i] = __shfl_up(x[i], 1);
+    for (int i = 0; i < RMT_V; ++i) xup[i] = rmt_lane_up1(x[i]);
     if (lane == 63) {
 #pragma unroll
         for (int i = 0; i < RMT_V; ++i) sh.bnd[buf][wave][i] = x[i];

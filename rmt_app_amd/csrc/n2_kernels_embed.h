@@ -81,15 +81,8 @@ __device__ __forceinline__ double rmt_cosh(double x) { return cosh(x); }
 __device__ __forceinline__ double rmt_atan(double x) { return atan(x); }
 __device__ __forceinline__ double rmt_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ double rmt_max(double a, double b) { return fmax(a, b); }
-__device__ __forceinline__ float rmt_exp(float x) { return expf(x); }
-__device__ __forceinline__ float rmt_exp10(float x) { return exp10f(x); }
-__device__ __forceinline__ float rmt_exp2(float x) { return exp2f(x); }
 __device__ __forceinline__ float rmt_expm1(float x) { return expm1f(x); }
-__device__ __forceinline__ float rmt_log(float x) { return logf(x); }
-__device__ __forceinline__ float rmt_log10(float x) { return log10f(x); }
-__device__ __forceinline__ float rmt_log2(float x) { return log2f(x); }
 __device__ __forceinline__ float rmt_log1p(float x) { return log1pf(x); }
-__device__ __forceinline__ float rmt_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ float rmt_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ float rmt_pow(float x, float y) { return powf(x, y); }
 __device__ __forceinline__ float rmt_sin(float x) { return sinf(x); }
@@ -264,8 +257,28 @@ __device__ __forceinline__ double rmt_exp(double x) { return exp(x); }
 __device__ __forceinline__ double rmt_exp10(double x) { return exp10(x); }
 __device__ __forceinline__ double rmt_exp2(double x) { return exp2(x); }
 #endif
+#if RMT_FAST_MATH && !defined(RMT_HOST_EMULATION)
+// fp32: the hardware transcendental instructions (v_rcp_f32, v_exp_f32, v_log_f32, v_sqrt_f32; ~1 ulp)
+__device__ __forceinline__ float rmt_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float rmt_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float rmt_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float rmt_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float rmt_exp10(float x) { return __builtin_amdgcn_exp2f(x * 3.32192809488736235f); }
+__device__ __forceinline__ float rmt_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+__device__ __forceinline__ float rmt_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float rmt_log10(float x) { return __builtin_amdgcn_logf(x) * 0.301029995663981195f; }
+__device__ __forceinline__ float rmt_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
 __device__ __forceinline__ float rmt_rcp(float b) { return 1.0f / b; }
 __device__ __forceinline__ float rmt_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float rmt_exp(float x) { return expf(x); }
+__device__ __forceinline__ float rmt_exp2(float x) { return exp2f(x); }
+__device__ __forceinline__ float rmt_exp10(float x) { return exp10f(x); }
+__device__ __forceinline__ float rmt_log(float x) { return logf(x); }
+__device__ __forceinline__ float rmt_log2(float x) { return log2f(x); }
+__device__ __forceinline__ float rmt_log10(float x) { return log10f(x); }
+__device__ __forceinline__ float rmt_sqrt(float x) { return sqrtf(x); }
+#endif
 
 RMT_KINETICS_SOURCE
 

@@ -101,7 +101,8 @@ const char* rmt_n2_kernel_template(void);
 int rmt_n2_create(const rmt_n2_plan* plan, rmt_n2_handle** out);
 void rmt_n2_destroy(rmt_n2_handle* h);
 int rmt_n2_set_stream(rmt_n2_handle* h, void* hip_stream);
-/* replace the per-member constants (same E) without recompiling */
+/* replace the per-member constants (same E) without recompiling; fields that the code object's
+ * prelude baked in as literals (#define RMT_MC_<FIELD>) are not affected */
 int rmt_n2_set_members(rmt_n2_handle* h, const double* members);
 
 int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt);

@@ -94,6 +94,18 @@ class N2Device:
         s = self.torch.cuda.current_stream(self.device).cuda_stream
         hipbind.check(hipbind.lib().rmt_n2_set_stream(self.h, C.c_void_p(s)))
 
+    def set_members(self, members):
+        """Replace the per-reactor constant rows (same E) without recompiling - e.g. the next
+        point of a sweep.  Not available when member fields were baked into the kernel as literals
+        (``specialize``): those fields would silently keep their old values."""
+        if any(k.startswith("RMT_MC_") for k in self.defines):
+            raise hipbind.RmtN2Error("this kernel was specialised on its member rows "
+                                     "(N2Device(..., specialize=False) keeps them run-time)")
+        members = np.ascontiguousarray(members, dtype=np.float64).reshape(self.E, -1)
+        assert members.shape[1] == plan.MEMBER_FIXED + self.mech.S
+        self.members = members
+        hipbind.check(hipbind.lib().rmt_n2_set_members(self.h, members.ctypes.data_as(C.POINTER(C.c_double))))
+
     def set_mode(self, mode):
         hipbind.check(hipbind.lib().rmt_n2_set_mode(self.h, {"auto": 0, "reg": 1, "mem": 2, "chain": 3}[mode]))
 

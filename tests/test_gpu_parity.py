@@ -488,3 +488,28 @@ def test_n1_ensemble_one_reactor_per_lane():
     one["feed"]["concentration"] = (c0/c0.sum())*5.0e6/(INP.R_CONST*one["operating-conditions"]["temperature"])
     single = rmtExe(one)["resModel"][0]
     np.testing.assert_allclose(packs[33]["dataYs"], single["dataYs"], rtol=1e-9)
+
+
+def test_set_members_switches_operating_point_without_recompiling():
+    N = 128
+    mech = plan.Mechanism(INP.dme_notebook_input())
+    def rows_for(T):
+        m2 = INP.dme_notebook_input()
+        m2["operating-conditions"]["temperature"] = T
+        return plan.member_constants(m2, mech, N)
+    (nmA, rowA), (nmB, rowB) = rows_for(523), rows_for(540)
+    dev = N2Device(mech, np.array([rowA, rowA]), N, specialize=False)
+    dev.set_members(np.array([rowB, rowA]))
+    y = dev.to_device(np.array([plan.initial_state(nmB, mech, N), plan.initial_state(nmA, mech, N)]))
+    dev.rk4(y, 2e-6, 50)
+    fresh = N2Device(mech, np.array([rowB, rowA]), N, specialize=False)
+    y2 = fresh.to_device(np.array([plan.initial_state(nmB, mech, N), plan.initial_state(nmA, mech, N)]))
+    fresh.rk4(y2, 2e-6, 50)
+    np.testing.assert_array_equal(y.cpu().numpy(), y2.cpu().numpy())
+    assert np.max(np.abs(y.cpu().numpy()[0] - y.cpu().numpy()[1])) > 1e-6
+    spec = N2Device(mech, np.array([rowA, rowA]), N)          # specialised: refuses
+    from rmt_app_amd.hipbind import RmtN2Error
+    with pytest.raises(RmtN2Error):
+        spec.set_members(np.array([rowB, rowA]))
+    for d in (dev, fresh, spec):
+        d.close()

@@ -41,7 +41,8 @@ def template():
 # ----------------------------------------------------------------------------- C ABI
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "rmt_n2.h")).read()
-    declared = set(re.findall(r"\b(rmt_n2_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(rmt_n[12]_[a-z0-9_]+)\s*\(", hdr))
+    assert {"rmt_n1_profile", "rmt_n2_ros4", "rmt_n2_multistep", "rmt_n2_set_members"} <= declared
     assert {"rmt_n2_create", "rmt_n2_rhs", "rmt_n2_rk4", "rmt_n2_rk45", "rmt_n2_status",
             "rmt_n2_destroy", "rmt_n2_last_error", "rmt_n2_compile"} <= declared
     L = ctypes.CDLL(hipbind.LIB_PATH)

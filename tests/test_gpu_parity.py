@@ -513,3 +513,26 @@ def test_set_members_switches_operating_point_without_recompiling():
         spec.set_members(np.array([rowB, rowA]))
     for d in (dev, fresh, spec):
         d.close()
+
+
+@pytest.mark.parametrize("name,N,t1,dt", [("ch4", 100, 2.0, 1e-3), ("syn12", 64, 0.02, 2e-6)])
+def test_ros4_other_mechanisms_match_explicit(name, N, t1, dt):
+    """The stiff stepper is mechanism-generic: adiabatic 3-species CH4 (Tm == 0) and the
+    12-species / 8-reaction mechanism (13x13 node Jacobians) against RK4 at a small dt."""
+    mi, mech, nm, dev = make_device(name, N, block=64 if N <= 64 else 128, npt=1)
+    IV = plan.initial_state(nm, mech, N)
+    y = dev.to_device(IV)
+    dev.ros4(y, 0.0, t1, 1e-7, 1e-10, 1e-6, 10**6)
+    assert not dev.status().any()
+    st = dev.rk45_stats()
+    ref = dev.to_device(IV)
+    n = int(round(t1/dt))
+    dev.rk4(ref, t1/n, n)
+    assert not dev.status().any()
+    V = mech.V
+    a, b = y.cpu().numpy().reshape(V, N), ref.cpu().numpy().reshape(V, N)
+    scale = np.max(np.abs(b), axis=1, keepdims=True)
+    scale[scale == 0] = 1.0
+    assert np.max(np.abs(a - b)/scale) < 5e-6
+    assert int(st["accepted"][0]) < n//5
+    dev.close()

@@ -87,6 +87,30 @@ def cpu_baseline(mech, rows, IV, N_NODES, seconds=12.0):
                       "generated kernel source, g++ -O2 -fopenmp" % (E, N_NODES, steps, t_used)}
 
 
+def accuracy_vs_scipy_reference():
+    """Second half of BASELINE.json's metric ("max |dMoFri| vs SciPy ref"): the reference's own
+    test input (tests/test_rmt_N1_DME.py, its default 20-node mesh, 0.5 s) integrated on the device
+    by the explicit and by the stiff stepper, against the committed golden of the REFERENCE run
+    under LSODA rtol=1e-10/atol=1e-12 (tests/golden/g4_tight_dme_script_lsoda.npz, G4); max over the
+    5 output times of the relative difference of outlet mole fractions and temperature."""
+    import inputs as INP
+    from rmt_app_amd import rmtExe
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g4_tight_dme_script_lsoda.npz"))
+    out = {"reference": "PyREMOT RHS under SciPy LSODA rtol=1e-10 (golden G4), zNo=20, t=0.1..0.5 s"}
+    for ivp, extra in (("hip-rk4", {"dt": 2.5e-6}), ("hip-ros4", {"rtol": 3e-7, "atol": 3e-10})):
+        mi = INP.dme_script_input(ivp=ivp)
+        mi["solver-config"].update(dict(extra, quiet=True))
+        t0 = time.perf_counter()
+        dp = rmtExe(mi)["resModel"]["dataPack"]
+        wall = time.perf_counter() - t0
+        worst = 0.0
+        for k in range(5):
+            a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
+            worst = max(worst, float(np.max(np.abs(a - b)/np.abs(b))))
+        out[ivp] = {"max_rel_outlet_MoFri_T": worst, "wall_s": round(wall, 3), **extra}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +188,7 @@ def main():
     if rank == 0:
         assert outlet.shape == (total, mech.V) and bool(torch.isfinite(outlet).all())
 
+    dev.close()
     if rank == 0:
         node_steps = world*E*n_nodes*args.steps
         value = node_steps/tmax
@@ -201,8 +226,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)
+            line["accuracy"] = accuracy_vs_scipy_reference()
         print(json.dumps(line))
-    dev.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

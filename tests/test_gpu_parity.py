@@ -390,14 +390,14 @@ def test_rmtexe_ros4_end_to_end_vs_tight_scipy_reference(name):
     outlet mole fractions and temperature <= 1e-6 vs the reference under LSODA rtol 1e-10."""
     g = np.load(os.path.join(G, "g4_tight_%s_lsoda.npz" % name))
     mi = INP.ALL_N2_INPUTS[name](ivp="hip-ros4")
-    mi["solver-config"].update({"quiet": True, "rtol": 1e-6, "atol": 1e-9})
+    mi["solver-config"].update({"quiet": True})          # default tolerances (3e-7 / 3e-10)
     res = rmtExe(mi)
     dp = res["resModel"]["dataPack"]
     worst = 0.0
     for k in range(5):
         a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
         worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
-    assert worst < 1e-6, worst
+    assert worst < 2e-7, worst                           # requirement: 1e-6
     st = res["resModel"]["device-stats"]
     assert 200 < st["steps"] < 3000, st
 

@@ -536,3 +536,33 @@ def test_ros4_other_mechanisms_match_explicit(name, N, t1, dt):
     assert np.max(np.abs(a - b)/scale) < 5e-6
     assert int(st["accepted"][0]) < n//5
     dev.close()
+
+
+@pytest.mark.parametrize("ivp,extra,tol", [("hip-rk4", {"dt": 2e-6}, 1e-9), ("hip-ros4", {}, 1e-6),
+                                           ("hip-rk45", {"rtol": 1e-8, "atol": 1e-11}, 1e-6)])
+def test_rmtexe_isothermal_variant(ivp, extra, tol):
+    """process-type 'iso-thermal' (V = S, T == Tf; pbHomoReactor.py:3469-3470, 3883-3884, 4102)
+    end to end on every integrator against the oracle's RK4 of the same model."""
+    mi = INP.dme_notebook_input(ivp=ivp, process_type="iso-thermal", period=0.01)
+    mi["solver-config"].update(dict(extra, quiet=True, tNo=2))
+    dp = rmtExe(mi)["resModel"]["dataPack"]
+    pr = O.setup_n2(mi, 20)
+    f = O.make_rhs_vec(pr)
+    yv = pr["IV"]
+    for k in range(2):
+        yv = O.rk4(0.005*k, 0.005*(k + 1), 2500, yv, f, keep=False)
+        want = O.pack_interval(yv, pr, 0.005*(k + 1))
+        assert dp[k]["dataYs"].shape == want["dataYs"].shape == (7, 20)
+        assert np.max(np.abs(dp[k]["dataYs"] - want["dataYs"])/np.abs(want["dataYs"])) < tol
+        np.testing.assert_array_equal(dp[k]["dataYs"][6], 523.0)
+        assert np.shape(dp[k]["dataYCons1"]) == (6, 20) and np.shape(dp[k]["dataYTemp1"]) == (20,)
+
+
+def test_rmtexe_fp32_dtype_runs_and_is_single_precision_accurate():
+    mi = INP.dme_notebook_input(ivp="hip-rk4", period=0.004)
+    mi["solver-config"].update({"dt": 2e-6, "quiet": True, "tNo": 1, "dtype": "fp32", "zNo": 64})
+    a = rmtExe(mi)["resModel"]["dataPack"][0]["dataYs"]
+    mi["solver-config"]["dtype"] = "fp64"
+    b = rmtExe(mi)["resModel"]["dataPack"][0]["dataYs"]
+    err = np.max(np.abs(a - b)/np.abs(b))
+    assert 1e-9 < err < 2e-5, err

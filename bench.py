@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--npt", type=int, default=None)
     ap.add_argument("--lds", type=int, default=None, help="RK4 vectors kept in LDS (0,1,2)")
     ap.add_argument("--no-specialize", action="store_true", help="keep all member fields run-time")
+    ap.add_argument("--copt", default="", help="extra hipRTC compiler options (tuning experiments)")
     ap.add_argument("--define", action="append", default=[], help="kernel tuning macro NAME=VALUE")
     args = ap.parse_args()
 
@@ -154,14 +155,15 @@ def main():
     ens = DistributedEnsemble(
         mech, inputs, n_nodes, device=torch.device("cuda", local),
         compile_fn=lambda mdef: compile_mechanism(mech, n_nodes, block=args.block, npt=args.npt,
-                                                  lds_state=args.lds, defines={**defines, **mdef}, E=E))
+                                                  lds_state=args.lds, defines={**defines, **mdef}, E=E,
+                                                  extra_opts=args.copt))
     rows, IV = ens.rows, ens.IV
     assert rows.shape[0] == E
     if args.no_specialize:
         ens.member_defines.clear()
     dev = N2Device(mech, rows, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds,
                    defines={**defines, **ens.member_defines}, specialize=False,
-                   code=None if args.no_specialize else ens.code)
+                   code=None if args.no_specialize else ens.code, extra_opts=args.copt)
     dev.set_mode(args.mode)
     y = dev.to_device(IV)
 

@@ -100,6 +100,9 @@ def compile_cached(source, key, arch="gfx950", extra_opts=""):
     """Code objects are cached in-tree (rmt_app_amd/_kcache/<key>.hsaco): the directory travels
     with the repo snapshot, a cache under $HOME would not."""
     os.makedirs(CACHE_DIR, exist_ok=True)
+    if extra_opts:
+        import hashlib
+        key = "%s-%s" % (key, hashlib.sha256(extra_opts.encode()).hexdigest()[:8])
     path = os.path.join(CACHE_DIR, "%s-%s.hsaco" % (key, arch))
     if os.path.exists(path):
         with open(path, "rb") as f:

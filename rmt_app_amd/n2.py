@@ -231,7 +231,7 @@ def _progress(i, total, quiet):
 
 
 def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None, defines=None,
-                      arch="gfx950", E=None):
+                      arch="gfx950", E=None, extra_opts=""):
     """Code object for (mechanism, mesh size, members per rank) - what ensemble rank 0 compiles
     and broadcasts; pass the same E/block/npt/lds_state/defines to N2Device(code=...)."""
     b, n = choose_geometry(N, mech.V, fp32, E)
@@ -239,7 +239,7 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
     ls = mech.lds_state(fp32, block, npt, lds_state)
     tpl = hipbind.kernel_template()
     return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, ls, defines),
-                                  mech.digest(tpl, fp32, block, npt, ls, defines), arch)
+                                  mech.digest(tpl, fp32, block, npt, ls, defines), arch, extra_opts)
 
 
 def run_n2(modelInput, members_inputs=None):

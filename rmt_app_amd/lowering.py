@@ -568,8 +568,9 @@ class Lowered:
         body = "\n".join(lines)
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
         return (
+            "template <typename FL>\n"
             "__device__ __forceinline__ void %s(const real T, const real P, const real* __restrict__ x,\n"
-            "        const real* __restrict__ C, real* __restrict__ r, rmt_flags_t& flag) {\n%s\n%s\n}\n"
+            "        const real* __restrict__ C, real* __restrict__ r, FL& flag) {\n%s\n%s\n}\n"
             % (fname, body, outs))
 
 

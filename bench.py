@@ -111,6 +111,29 @@ def accuracy_vs_scipy_reference():
     return out
 
 
+def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
+    """The user-visible job behind the throughput number: every member of this rank's sweep
+    integrated over the full 0.5 s transient with the stiff Rosenbrock stepper (default
+    tolerances); the explicit RK4 time is steps*ms_per_step = 250000 steps at dt = 2e-6 s."""
+    import torch
+    from rmt_app_amd.n2 import N2Device
+    from rmt_app_amd.settings import DEVICE_DEFAULTS as D
+    dev = N2Device(mech, rows, n_nodes, block=256, npt=1)
+    y = dev.to_device(IV)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev.ros4(y, 0.0, t_end, D["ros4-rtol"], D["ros4-atol"], D["ros4-h0"], 10**7)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    flags = dev.status()
+    st = dev.rk45_stats()
+    dev.close()
+    tot = st["accepted"] + st["rejected"]
+    return {"integrator": "hip-ros4", "t_end_s": t_end, "wall_s": round(wall, 4), "flags_ok": not bool(flags.any()),
+            "steps_per_reactor_min_median_max": [int(tot.min()), int(np.median(tot)), int(tot.max())],
+            "rtol": D["ros4-rtol"], "atol": D["ros4-atol"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +252,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)
             line["accuracy"] = accuracy_vs_scipy_reference()
+            line["time_to_solution"] = time_to_solution(mech, rows, IV, n_nodes)
+            line["time_to_solution"]["rk4_equivalent_wall_s"] = round(250000*tmax/args.steps, 3)
         print(json.dumps(line))
     if distributed:
         dist.barrier()

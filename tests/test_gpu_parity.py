@@ -566,3 +566,43 @@ def test_rmtexe_fp32_dtype_runs_and_is_single_precision_accurate():
     b = rmtExe(mi)["resModel"]["dataPack"][0]["dataYs"]
     err = np.max(np.abs(a - b)/np.abs(b))
     assert 1e-9 < err < 2e-5, err
+
+
+def test_full_size_16384_nodes_chain_vs_memory_stepper_and_properties():
+    """BASELINE configs[2] size (16384 nodes): the chained on-chip stepper and the memory-resident
+    one are independent code paths for the cross-block carries - they must agree; plus
+    size-independent properties: mole fractions sum to one, pressure falls monotonically,
+    and halving dt changes the answer by O(dt^4)."""
+    N = 16384
+    mi, mech, nm, dev = make_device("dme_nb", N)
+    IV = plan.initial_state(nm, mech, N)
+    outs = {}
+    for mode, dt, n in (("chain", 2e-6, 40), ("mem", 2e-6, 40), ("chain", 1e-6, 80), ("chain", 4e-6, 20)):
+        dev.set_mode(mode)
+        y = dev.to_device(IV)
+        dev.rk4(y, dt, n)
+        assert not dev.status().any()
+        outs[(mode, dt)] = y.cpu().numpy()[0].reshape(7, N)
+    a, b = outs[("chain", 2e-6)], outs[("mem", 2e-6)]
+    assert np.max(np.abs(a - b)) < 1e-12
+    conc = a[:6]*nm["Cmax"]
+    x = conc/conc.sum(0)
+    assert np.max(np.abs(x.sum(0) - 1.0)) < 1e-14
+    e1 = np.max(np.abs(outs[("chain", 4e-6)] - outs[("chain", 2e-6)]))
+    e2 = np.max(np.abs(outs[("chain", 2e-6)] - outs[("chain", 1e-6)]))
+    assert e2 < e1/8 or e1 < 1e-13          # 4th order: ratio ~16
+    # the RHS's pressure profile (recomputed by the oracle from the device state) is monotone
+    pr = O.setup_n2(mi, N)
+    _, _, _, _, P = O.neighbourhood(pr, a.reshape(1, 7, N))
+    assert np.all(np.diff(P[0]) < 0) and P[0, 0] == 5.0e6
+    dev.close()
+
+
+def test_adaptive_steppers_report_step_budget_exhaustion():
+    """max-steps too small: RMT_FLAG_STEP -> RuntimeError (the reference does a bare `raise` when
+    solve_ivp reports failure, pbHomoReactor.py:3614-3615)."""
+    for ivp in ("hip-rk45", "hip-ros4"):
+        mi = INP.dme_notebook_input(ivp=ivp)
+        mi["solver-config"].update({"quiet": True, "max-steps": 5})
+        with pytest.raises(RuntimeError, match="step"):
+            rmtExe(mi)

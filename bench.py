@@ -229,7 +229,7 @@ def main():
                        "members_per_gpu": E, "nodes": n_nodes, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,
                        "kernel": "rmt_n2_rk4_%s block=%d npt=%d lds_state=%d" % (
-                           "reg" if (args.mode != "mem" and n_nodes <= dev.block*dev.npt) else "mem",
+                           "mem" if args.mode == "mem" else ("reg" if n_nodes <= dev.block*dev.npt else "chain"),
                            dev.block, dev.npt, dev.lds_state)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved/HBM_PEAK_GBS,

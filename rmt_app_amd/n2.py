@@ -67,8 +67,9 @@ class N2Device:
             specialize = self.E >= 2
         if specialize:
             self.defines.update(plan.uniform_member_defines(members, mech.S))
-        src = mech.source(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
-        key = mech.digest(tpl, self.fp32, self.block, self.npt, self.lds_state, self.defines)
+        # (the user's lds_state, possibly None, is what selects the per-kernel defaults)
+        src = mech.source(tpl, self.fp32, self.block, self.npt, lds_state, self.defines)
+        key = mech.digest(tpl, self.fp32, self.block, self.npt, lds_state, self.defines)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         if code is None:      # an ensemble rank may receive rank 0's code object instead
             code = hipbind.compile_cached(src, key, arch, extra_opts)
@@ -236,10 +237,9 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
     and broadcasts; pass the same E/block/npt/lds_state/defines to N2Device(code=...)."""
     b, n = choose_geometry(N, mech.V, fp32, E)
     block, npt = int(block or b), int(npt or n)
-    ls = mech.lds_state(fp32, block, npt, lds_state)
     tpl = hipbind.kernel_template()
-    return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, ls, defines),
-                                  mech.digest(tpl, fp32, block, npt, ls, defines), arch, extra_opts)
+    return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, lds_state, defines),
+                                  mech.digest(tpl, fp32, block, npt, lds_state, defines), arch, extra_opts)
 
 
 def run_n2(modelInput, members_inputs=None):

@@ -144,6 +144,7 @@ class Mechanism:
             "#define RMT_BLOCK %d" % block,
             "#define RMT_NPT %d" % npt,
             "#define RMT_LDS_STATE %d" % self.lds_state(fp32, block, npt, lds_state),
+            "#define RMT_LDS_STATE_CHAIN %d" % self.lds_state(fp32, block, npt, lds_state, chained=True),
         ] + ["#define %s %s" % (k, v) for k, v in sorted((defines or {}).items())] + [
             "typedef %s real;" % ("float" if fp32 else "double"),
             "__device__ static const real RMT_MW[RMT_S] = %s;" % arr(self.MW),
@@ -193,12 +194,19 @@ class Mechanism:
             self._opt = self.lowered.optimize() if self.optimize else self.lowered
         return self._opt
 
-    def lds_state(self, fp32, block, npt, want=None):
+    def lds_state(self, fp32, block, npt, want=None, chained=False):
         """How many of the two long-lived RK4 vectors (y_n, K accumulator) the on-chip stepper
-        keeps in LDS instead of VGPRs: as many as fit in 144 KiB of the CU's 160 KiB."""
+        keeps in LDS instead of VGPRs.  Default: as many as fit in 144 KiB of the CU's 160 KiB,
+        except for the single-workgroup kernel at 512 threads x 2 nodes with V <= 8, whose 249
+        VGPRs hold everything without scratch (measured 12.3 vs 11.9 G node-steps/s); the chained
+        kernel always prefers LDS (6.4 vs 3.4)."""
         per = self.V*block*npt*(4 if fp32 else 8)
         fit = min(2, (144*1024)//per)
-        return fit if want is None else min(int(want), fit)
+        if want is not None:
+            return min(int(want), fit)
+        if not chained and block == 512 and npt == 2 and self.V <= 8 and not fp32:
+            return 0
+        return fit
 
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""

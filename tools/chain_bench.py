@@ -29,7 +29,7 @@ def run(N, E, steps, mode, block=None, npt=None, lds=None):
 
 print("| nodes N | reactors E | stepper | steps | kernel ms | us/step | node-steps/s | flags |")
 print("|---|---|---|---|---|---|---|---|")
-run(1024, 1, 2000, "reg")
+run(1024, 1, 2000, "reg", 512, 2)
 for b, n in ((64, 1), (64, 2), (128, 1), (128, 2), (256, 1), (256, 2)):
     run(1024, 1, 2000, "chain", b, n)
 run(4096, 1, 1000, "mem")

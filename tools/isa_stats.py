@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import inputs as INP
 from rmt_app_amd import plan, hipbind
 name = sys.argv[1] if len(sys.argv) > 1 else "dme_nb"
-block, npt, lds = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 512), (3, 2), (4, 2)))
+block, npt = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 512), (3, 2)))
+lds = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].lstrip("-").isdigit() else None
 kern = sys.argv[5] if len(sys.argv) > 5 else "rmt_n2_rk4_reg"
 defines = dict(a.split("=", 1) for a in sys.argv[6:])
 mech = plan.Mechanism(INP.ALL_N2_INPUTS[name]())
@@ -21,7 +22,7 @@ ins = [l.split("\t")[1].split()[0] for l in body.split("\n") if "\t" in l and le
 c = collections.Counter(ins)
 f64 = sum(v for k, v in c.items() if "f64" in k)
 valu = sum(v for k, v in c.items() if k.startswith("v_"))
-print("%s %s %dx%d lds%d %s: total %d valu %d f64 %d (per node-step %.0f) readlane+writelane %d cndmask %d s_mov %d ds %d scratch %d" % (
+print("%s %s %dx%d lds%s %s: total %d valu %d f64 %d (per node-step %.0f) readlane+writelane %d cndmask %d s_mov %d ds %d scratch %d" % (
     name, kern, block, npt, lds, defines, len(ins), valu, f64, f64/npt, c["v_readlane_b32"] + c["v_writelane_b32"],
     c["v_cndmask_b32_e64"] + c["v_cndmask_b32_e32"], c["s_mov_b32"], sum(v for k, v in c.items() if k.startswith("ds_")),
     sum(v for k, v in c.items() if k.startswith("scratch"))))

@@ -118,7 +118,7 @@ def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
     import torch
     from rmt_app_amd.n2 import N2Device
     from rmt_app_amd.settings import DEVICE_DEFAULTS as D
-    dev = N2Device(mech, rows, n_nodes, block=256, npt=1)
+    dev = N2Device(mech, rows, n_nodes, block=256, npt=1, features=("ros4",))
     y = dev.to_device(IV)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

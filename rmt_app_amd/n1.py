@@ -56,7 +56,7 @@ def run_n1(modelInput, members_inputs=None):
     rows1 = np.ascontiguousarray(np.array([r for _, r in pairs]))
     # the handle is an N2 handle (same generated module); its N2 member rows are not used here
     dummy = np.array([plan.member_constants(mi, mech, 64)[1] for mi in inputs])
-    dev = N2Device(mech, dummy, 64, block=64, npt=1, specialize=False)
+    dev = N2Device(mech, dummy, 64, block=64, npt=1, specialize=False, features=("n1",))
     try:
         torch = dev.torch
         V1 = mech.S + (1 if mech.iso else 2)

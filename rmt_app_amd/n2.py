@@ -45,7 +45,8 @@ class N2Device:
     """One compiled mechanism + E packed member rows on one GPU."""
 
     def __init__(self, mech, members, N, fp32=False, block=None, npt=None, device=None,
-                 extra_opts="", lds_state=None, defines=None, code=None, specialize=None):
+                 extra_opts="", lds_state=None, defines=None, code=None, specialize=None,
+                 features=()):
         torch = _torch()
         self.torch = torch
         self.mech, self.N, self.fp32 = mech, int(N), bool(fp32)
@@ -61,6 +62,11 @@ class N2Device:
         tpl = hipbind.kernel_template()
         self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
         self.defines = dict(defines or {})
+        # optional kernel families: "ros4" (stiff stepper), "n1" (steady-state model); their
+        # unrolled VxV linear algebra is most of the JIT time, so they are compiled on demand
+        self.features = tuple(features)
+        for f in self.features:
+            self.defines[{"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}[f]] = "1"
         # sweep-invariant member fields become literals (frees SGPRs); a single reactor is NOT
         # specialised by default - every new operating point would cost a 2-3 s JIT
         if specialize is None:
@@ -160,6 +166,8 @@ class N2Device:
         """In place: stiff Rosenbrock(4,3) integration from t0 to t1 with per-reactor step control
         (needs a code object generated with block <= 256)."""
         self._chk_state(y)
+        if "ros4" not in self.features:
+            raise hipbind.RmtN2Error("create the device with features=('ros4',) to use the stiff stepper")
         hipbind.check(hipbind.lib().rmt_n2_ros4(self.h, C.c_void_p(y.data_ptr()), float(t0), float(t1),
                                                 float(rtol), float(atol), float(h0), int(max_steps),
                                                 C.c_void_p(self._stats.data_ptr())))
@@ -271,7 +279,8 @@ def run_n2(modelInput, members_inputs=None):
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:      # one VxV matrix per lane: at most 256 threads
         block, npt = min(256, 64*((zNo + 63)//64)), 1
-    dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt)
+    dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt,
+                   features=("ros4",) if ivp == "hip-ros4" else ())
     try:
         IV = np.array([plan.initial_state(nm, mech, zNo) for nm, _ in named_rows])
         y = dev.to_device(IV)

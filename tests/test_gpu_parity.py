@@ -368,7 +368,7 @@ def test_ros4_vs_oracle_controller():
     """Stiff Rosenbrock(4,3) with per-reactor step control vs the oracle's restatement (exact
     bidiagonal solves there, Jacobi sweeps to 1e-12 here): same step history, same end state."""
     N = 20
-    mi, mech, nm, dev = make_device("dme_script", N, block=64, npt=1)
+    mi, mech, nm, dev = make_device("dme_script", N, block=64, npt=1, features=("ros4",))
     y = dev.to_device(plan.initial_state(nm, mech, N))
     rtol, atol, h0, t1 = 1e-6, 1e-9, 1e-5, 0.1
     dev.ros4(y, 0.0, t1, rtol, atol, h0, 10**6)
@@ -414,7 +414,7 @@ def test_ros4_1024_nodes_ensemble_matches_explicit():
         nm, row = plan.member_constants(m2, mech, N)
         rows.append(row), named.append(nm)
     IV = np.array([plan.initial_state(nm, mech, N) for nm in named])
-    dev = N2Device(mech, np.array(rows), N, block=256, npt=1)
+    dev = N2Device(mech, np.array(rows), N, block=256, npt=1, features=("ros4",))
     y = dev.to_device(IV)
     dev.ros4(y, 0.0, 4e-3, 1e-7, 1e-10, 1e-6, 10**6)
     assert not dev.status().any()
@@ -519,7 +519,7 @@ def test_set_members_switches_operating_point_without_recompiling():
 def test_ros4_other_mechanisms_match_explicit(name, N, t1, dt):
     """The stiff stepper is mechanism-generic: adiabatic 3-species CH4 (Tm == 0) and the
     12-species / 8-reaction mechanism (13x13 node Jacobians) against RK4 at a small dt."""
-    mi, mech, nm, dev = make_device(name, N, block=64 if N <= 64 else 128, npt=1)
+    mi, mech, nm, dev = make_device(name, N, block=64 if N <= 64 else 128, npt=1, features=("ros4",))
     IV = plan.initial_state(nm, mech, N)
     y = dev.to_device(IV)
     dev.ros4(y, 0.0, t1, 1e-7, 1e-10, 1e-6, 10**6)

@@ -32,7 +32,7 @@ ref = y.cpu().numpy().reshape(E, mech.V, N)[:, :, -1]
 print("| hip-rk4 dt=2e-6 | %d | %d | %g | %d | %.3f | - |" % (E, N, T_END, n, w), flush=True)
 dev.close()
 for rtol in (1e-5, 1e-6, 1e-7):
-    dev = N2Device(mech, rows, N, block=256, npt=1, defines=DEFS)
+    dev = N2Device(mech, rows, N, block=256, npt=1, defines=DEFS, features=("ros4",))
     y = dev.to_device(IV)
     t0 = time.perf_counter(); dev.ros4(y, 0.0, T_END, rtol, 1e-3*rtol, 1e-5, 10**7); torch.cuda.synchronize(); w = time.perf_counter() - t0
     fl = dev.status(); st = dev.rk45_stats()

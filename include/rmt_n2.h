@@ -61,6 +61,7 @@ extern "C" {
 #define RMT_N2_FLAG_OVERFLOW 4u  /* Python: OverflowError("math range error")         */
 #define RMT_N2_FLAG_NONFINITE 8u /* a state/derivative became NaN or Inf              */
 #define RMT_N2_FLAG_STEP 16u     /* rk45: step size underflow / max steps exceeded    */
+#define RMT_N2_FLAG_PRESSURE 32u /* model M2: Newton sweeps of the pressure march did not converge */
 
 /* member row layout: doubles per reactor = 16 + S (see rmt_app_amd/csrc/n2_kernels.inc M_*) */
 #define RMT_N2_MEMBER_FIXED 16

@@ -31,10 +31,10 @@ static void emu_rhs_one(const RmtMember& m, const real* y, real* dydt, int N, rm
         real ys[RMT_V], k[RMT_V];
         for (int i = 0; i < RMT_V; ++i) ys[i] = y[(size_t)i * N + z];
         RmtNode nd;
-        const preal a = rmt_node_pre(m, ys, nd);
+        const auto a = rmt_node_pre(m, ys, nd);
         rmt_node_post(m, nd, ys, up, P, k, flag);
         for (int i = 0; i < RMT_V; ++i) dydt[(size_t)i * N + z] = k[i];
-        P = a * P + m.beta;
+        P = rmt_pressure_next(m, a, P);      // N2: affine (pbHomoReactor.py:3979); M2: EOS velocity (pbReactor.py:1055)
         for (int i = 0; i < RMT_S; ++i) up[i] = rmt_max(ys[i], RMT_EPS);
 #if !RMT_ISO
         up[RMT_S] = ys[RMT_S];

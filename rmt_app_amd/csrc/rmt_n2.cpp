@@ -343,7 +343,7 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
         return fail("the Rosenbrock kernel holds a VxV matrix per lane: generate the code object with "
                     "block <= 256 (got %d)", h->block);
     // 7 vector arrays + the VxV inverse per node (= V more "vector arrays")
-    if (ensure_work(h, 7 + (size_t)h->V)) return 1;
+    if (ensure_work(h, 8 + (size_t)h->V)) return 1;   // 7 stage arrays + VxV inverses + upwind coupling (model M2)
     const size_t nmask = (size_t)h->E * h->N;
     if (h->mask_elems < nmask) {
         if (h->d_mask) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->d_mask)); }

@@ -42,6 +42,8 @@ def expand_members(modelInput, spec):
         Ps = np.atleast_1d(np.asarray(spec.get("pressure", [modelInput['operating-conditions']['pressure']]), float))
         c0 = np.asarray(modelInput['feed']['concentration'], dtype=float)
         y0 = c0/c0.sum()
+        if modelInput.get('model') == "M2":
+            y0 = y0*1e-3            # model M2 takes its feed in kmol/m^3 (pbReactor.py:609)
         out = []
         for T in Ts:
             for P in Ps:

@@ -15,17 +15,25 @@ from . import hipbind, plan
 from .lowering import FLAG_DIV0, FLAG_DOMAIN, FLAG_NONFINITE, FLAG_OVERFLOW, FLAG_STEP
 from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 
+FLAG_PRESSURE = 32
 DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "AM", "hip-ab3")
 
 
-def choose_geometry(N, V, fp32=False, E=None):
+def choose_geometry(N, V, fp32=False, E=None, chainable=True):
     """(block, nodes_per_thread) of the generated kernels for E reactors of N nodes.
+    ``chainable`` False (model M2: no chained-workgroup kernel): keep a reactor in ONE workgroup
+    whenever it fits (N <= 1024), else the memory-resident stepper walks it in 512-node blocks.
     The on-chip stepper holds block*npt nodes per workgroup; longer reactors are chained over
     several workgroups (rmt_n2_rk4_chain).  The table is what measured fastest on MI355X
     (profiles/round1_chain.md, round1_shapes.md):
       * big ensembles: 512 threads x 2 nodes (1024-node chunks, 2 waves/SIMD, y_n/acc in LDS);
       * little total work (E*N <= 32768 nodes, e.g. ONE reactor): 128-node chunks so that a
         single reactor spreads over up to 256 CUs (14.8 us/step at N=4096 vs 199 us on one CU)."""
+    if not chainable:
+        for block in (64, 128, 256, 512):
+            if N <= block:
+                return block, 1
+        return (512, 2) if (N <= 1024 and V <= 8) else (512, 1)
     if N > 256 and E is not None and E*N <= 256*128:
         return 128, 1
     for block in (64, 128, 256, 512):
@@ -56,7 +64,7 @@ class N2Device:
         assert members.shape[1] == plan.MEMBER_FIXED + mech.S
         self.E = members.shape[0]
         self.members = members
-        b, n = choose_geometry(self.N, mech.V, fp32, self.E)
+        b, n = choose_geometry(self.N, mech.V, fp32, self.E, chainable=getattr(mech, 'model', 'N2') != 'M2')
         self.block, self.npt = int(block or b), int(npt or n)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         tpl = hipbind.kernel_template()
@@ -206,6 +214,9 @@ class N2Device:
             raise RuntimeError("adaptive step control failed (step underflow / max steps) in " + where)
         if f & FLAG_NONFINITE:
             raise FloatingPointError("state became NaN/Inf in " + where + " - step size too large?")
+        if f & FLAG_PRESSURE:
+            raise RuntimeError("model M2: the Newton sweeps of the pressure march did not converge in "
+                               + where + " - pass defines={'RMT_M2_NEWTON': 4} (pressure drop > 15 % of P)")
         raise RuntimeError("device error in " + where)
 
 
@@ -250,21 +261,73 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
                                   mech.digest(tpl, fp32, block, npt, lds_state, defines), arch, extra_opts)
 
 
-def run_n2(modelInput, members_inputs=None):
-    """runN2 on the device.  ``members_inputs``: optional list of modelInput dicts (one per
-    ensemble member, same mechanism); default = the single reactor described by modelInput."""
-    start = timer()
-    cfg = modelInput['solver-config']
-    ivp = cfg['ivp']
-    displayResult = cfg['display-result'] == "True"        # KeyError like the reference (:3337)
-    # the reference's "default" is SciPy's LSODA (pbHomoReactor.py:3576); its other stiff choices
-    # are BDF / Radau: all of them map to the device's stiff Rosenbrock stepper; the explicit
-    # SciPy pairs map to the device Dormand-Prince stepper.
+def resolve_ivp(ivp):
+    """the reference's "default" is SciPy's LSODA (pbHomoReactor.py:3576); its other stiff choices
+    are BDF / Radau: all of them map to the device's stiff Rosenbrock stepper; the explicit SciPy
+    pairs map to the device Dormand-Prince stepper."""
     ivp = {"default": "hip-ros4", "LSODA": "hip-ros4", "BDF": "hip-ros4", "Radau": "hip-ros4",
            "RK45": "hip-rk45", "RK23": "hip-rk45", "DOP853": "hip-rk45"}.get(ivp, ivp)
     if ivp not in DEVICE_IVPS:
         raise ValueError("`ivp` must be one of %s, 'default' or a SciPy method name (got %r)"
                          % (DEVICE_IVPS, ivp))
+    return ivp
+
+
+def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_interval):
+    """The reference's time loop (pbHomoReactor.py:3589-3690, pbReactor.py:711-762): one device
+    launch per output interval; ``on_interval(i, t1, Y_host)`` packs the end state."""
+    tNo = len(opTSpan) - 1
+    stats = {"steps": 0, "rhs_evals": 0, "node_steps": 0, "accepted": None, "rejected": None}
+    _progress(0, tNo + 1, quiet)
+    h_next = None
+    for i in range(tNo):
+        t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
+        _progress(i + 1, tNo + 1, quiet)
+        if ivp == "hip-rk4":
+            dt_req = float(cfg.get('dt', DEVICE_DEFAULTS['rk4-dt']))
+            n = max(1, int(round((t1 - t0)/dt_req)))
+            dev.rk4(y, (t1 - t0)/n, n, t0)
+            stats["steps"] += n
+            stats["rhs_evals"] += 4*n
+        elif ivp in ("AM", "hip-ab3"):
+            # the reference's plug point: PreCorr3 with n fixed steps per output interval,
+            # n from solverSetting['T1']['ode-solver']['PreCorr3']['n'] (pbHomoReactor.py:3572,3601)
+            n = int(cfg.get('n', solverSetting['T1']['ode-solver']['PreCorr3']['n']))
+            dev.multistep(y, abs(t1 - t0)/n, n, "PreCorr3" if ivp == "AM" else "AdBash3", t0)
+            stats["steps"] += n
+            stats["rhs_evals"] += (2*n + 6) if ivp == "AM" else (n + 8)
+        elif ivp == "hip-ros4":
+            h_next = float(cfg.get('h0', DEVICE_DEFAULTS['ros4-h0'])) if i == 0 else h_next
+            dev.ros4(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['ros4-rtol'])),
+                     float(cfg.get('atol', DEVICE_DEFAULTS['ros4-atol'])), h_next,
+                     int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
+        else:
+            dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
+                     float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])),
+                     float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0'])),
+                     int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
+        dev.raise_on_flags()
+        if ivp in ("hip-rk45", "hip-ros4"):
+            st = dev.rk45_stats()
+            h_next = float(np.min(st["h_last"]))
+            stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
+            stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
+        on_interval(i, t1, y.cpu().numpy().astype(np.float64))
+    if stats["accepted"] is not None:
+        stats["steps"] = int(np.sum(stats["accepted"]))
+        per = 6 if ivp == "hip-rk45" else 3
+        stats["rhs_evals"] = int(np.sum(per*(stats["accepted"] + stats["rejected"])) + n_members*tNo)
+    stats["node_steps"] = stats["steps"]*zNo*(n_members if ivp != "hip-rk45" else 1)
+    return stats
+
+
+def run_n2(modelInput, members_inputs=None):
+    """runN2 on the device.  ``members_inputs``: optional list of modelInput dicts (one per
+    ensemble member, same mechanism); default = the single reactor described by modelInput."""
+    start = timer()
+    cfg = modelInput['solver-config']
+    displayResult = cfg['display-result'] == "True"        # KeyError like the reference (:3337)
+    ivp = resolve_ivp(cfg['ivp'])
     zNo = int(cfg.get('zNo', solverSetting['N2']['zNo']))
     tNo = int(cfg.get('tNo', solverSetting['N2']['tNo']))
     fp32 = cfg.get('dtype', 'fp64') in ('fp32', 'float32')
@@ -284,50 +347,13 @@ def run_n2(modelInput, members_inputs=None):
     try:
         IV = np.array([plan.initial_state(nm, mech, zNo) for nm, _ in named_rows])
         y = dev.to_device(IV)
-        opTSpan = np.linspace(0, opT, tNo + 1)
         packs = [[] for _ in inputs]
-        stats = {"steps": 0, "rhs_evals": 0, "node_steps": 0, "accepted": None, "rejected": None}
-        _progress(0, tNo + 1, quiet)
-        for i in range(tNo):
-            t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
-            _progress(i + 1, tNo + 1, quiet)
-            if ivp == "hip-rk4":
-                dt_req = float(cfg.get('dt', DEVICE_DEFAULTS['rk4-dt']))
-                n = max(1, int(round((t1 - t0)/dt_req)))
-                dev.rk4(y, (t1 - t0)/n, n, t0)
-                stats["steps"] += n
-                stats["rhs_evals"] += 4*n
-            elif ivp in ("AM", "hip-ab3"):
-                # the reference's plug point: PreCorr3 with n fixed steps per output interval,
-                # n from solverSetting['T1']['ode-solver']['PreCorr3']['n'] (pbHomoReactor.py:3572,3601)
-                n = int(cfg.get('n', solverSetting['T1']['ode-solver']['PreCorr3']['n']))
-                dev.multistep(y, abs(t1 - t0)/n, n, "PreCorr3" if ivp == "AM" else "AdBash3", t0)
-                stats["steps"] += n
-                stats["rhs_evals"] += (2*n + 6) if ivp == "AM" else (n + 8)
-            elif ivp == "hip-ros4":
-                h_next = float(cfg.get('h0', DEVICE_DEFAULTS['ros4-h0'])) if i == 0 else h_next
-                dev.ros4(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['ros4-rtol'])),
-                         float(cfg.get('atol', DEVICE_DEFAULTS['ros4-atol'])), h_next,
-                         int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
-            else:
-                dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
-                         float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])),
-                         float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0'])),
-                         int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
-            dev.raise_on_flags()
-            if ivp in ("hip-rk45", "hip-ros4"):
-                st = dev.rk45_stats()
-                h_next = float(np.min(st["h_last"]))
-                stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
-                stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
-            Yh = y.cpu().numpy().astype(np.float64)
+
+        def on_interval(i, t1, Yh):
             for e, (nm, _) in enumerate(named_rows):
                 packs[e].append(pack_interval(Yh[e], nm, mech, zNo, t1, modelId))
-        if stats["accepted"] is not None:
-            stats["steps"] = int(np.sum(stats["accepted"]))
-            per = 6 if ivp == "hip-rk45" else 3
-            stats["rhs_evals"] = int(np.sum(per*(stats["accepted"] + stats["rejected"])) + len(inputs)*tNo)
-        stats["node_steps"] = stats["steps"]*zNo*(len(inputs) if ivp != "hip-rk45" else 1)
+        stats = integrate_intervals(dev, y, cfg, ivp, np.linspace(0, opT, tNo + 1), len(inputs),
+                                    zNo, quiet, on_interval)
     finally:
         dev.close()
     elapsed = np.round(timer() - start, ROUND_FUN_ACCURACY)

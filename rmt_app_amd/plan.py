@@ -97,7 +97,13 @@ class Mechanism:
             if s not in compdb.componentSymbolList:
                 raise Exception("Component database is not up to date!")       # rmt.py:55-57
         self.S = len(self.compList)
-        self.processType = mi['operating-conditions']['process-type']
+        # "M2" (dimensional dynamic model, pbReactor.py:552-1165) has no process-type key: it is
+        # always non-iso-thermal; everything else on this path is the dimensionless N2/N1 pair
+        self.model = "M2" if mi.get('model') == "M2" else "N2"
+        if self.model == "M2":
+            self.processType = PROCESS_SETTING['NON-ISO-THER']
+        else:
+            self.processType = mi['operating-conditions']['process-type']
         self.iso = self.processType == PROCESS_SETTING['ISO-THER']
         self.V = self.S if self.iso else self.S + 1
         self.reactionDict = dict(mi['reactions'])
@@ -140,6 +146,7 @@ class Mechanism:
             "#define RMT_S %d" % S,
             "#define RMT_R %d" % R,
             "#define RMT_ISO %d" % (1 if self.iso else 0),
+            "#define RMT_MODEL %d" % (2 if self.model == "M2" else 0),
             "#define RMT_FP32 %d" % (1 if fp32 else 0),
             "#define RMT_BLOCK %d" % block,
             "#define RMT_NPT %d" % npt,
@@ -287,6 +294,57 @@ def member_constants(modelInput, mech, zNo):
     row[F["TM"]] = Tm
     row[F["CIN"]:F["CIN"] + mech.S] = SpCoi0/Cmax                      # :4090
     return named, row
+
+
+def member_constants_m2(modelInput, mech, zNo):
+    """Model M2 (pbReactor.py:552-700 setup, :845-1165 RHS): the packed row keeps the N2 layout
+    (MEMBER_FIELDS) with the meanings listed above the M2 node functions in csrc/n2_kernels.inc."""
+    mi = modelInput
+    P = mi['operating-conditions']['pressure']
+    T = mi['operating-conditions']['temperature']
+    ReSpec = mi['reactor']
+    ReInDi, ReLe = ReSpec['ReInDi'], ReSpec['ReLe']
+    PaDi, BeVoFr = ReSpec['PaDi'], ReSpec['BeVoFr']
+    CrSeAr = PI_CONST*(ReInDi**2)/4                                   # :592
+    VoFlRa0 = mi['feed']['volumetric-flowrate']
+    SpCoi0 = np.array(mi['feed']['concentration'], dtype=float)       # [kmol/m^3]
+    if SpCoi0.shape != (mech.S,):
+        raise ValueError("feed.concentration must have one entry per shell component")
+    SpCo0 = np.sum(SpCoi0)
+    GaMiVi = mi['feed']['mixture-viscosity']                          # :620
+    ExHe = mi['external-heat']
+    dz = ReLe/(zNo - 1)                                               # :629
+    InGaVe0 = VoFlRa0/(CrSeAr*BeVoFr)                                 # :973
+    ergB = ((1 - BeVoFr)**2)/(BeVoFr**3)
+    ergD = (1 - BeVoFr)/(BeVoFr**3)
+    named = {"CrSeAr": CrSeAr, "SpCoi0": SpCoi0, "SpCo0": SpCo0, "GaMiVi": GaMiVi, "dz": dz,
+             "P0": P, "T0": T, "VoFlRa0": VoFlRa0, "ReLe": ReLe, "InGaVe0": InGaVe0}
+    row = np.zeros(MEMBER_FIXED + mech.S)
+    F = MEMBER_FIELDS
+    row[F["CMAX"]] = 1.0
+    row[F["TF"]] = T
+    row[F["P0"]] = P
+    row[F["THETA_IN"]] = T                                            # T0, :1151
+    row[F["ALPHA_K"]] = dz*1.75*ergD/PaDi
+    row[F["BETA"]] = dz*150*GaMiVi*ergB/(PaDi**2)
+    row[F["RHO_K"]] = InGaVe0*BeVoFr*P/SpCo0
+    row[F["INV_CP0"]] = (1 - BeVoFr)*ReSpec['CaDe']*ReSpec['CaSpHeCa']   # :1123
+    row[F["F1"]] = 1/BeVoFr                                           # :1121
+    row[F["FT"]] = BeVoFr
+    row[F["INV_DZ"]] = 1.0/dz
+    row[F["UA"]] = ExHe['OvHeTrCo']*ExHe['EfHeTrAr']*1e-3             # rmtUtility.py:445-450
+    row[F["TM"]] = ExHe['MeTe']
+    row[F["CIN"]:F["CIN"] + mech.S] = SpCoi0                          # :1135
+    return named, row
+
+
+def initial_state_m2(named, mech, zNo):
+    """IV2D flattened (pbReactor.py:641-653): feed concentrations and feed temperature everywhere."""
+    IV = np.zeros((mech.V, zNo))
+    for i in range(mech.S):
+        IV[i, :] = named["SpCoi0"][i]
+    IV[mech.S, :] = named["T0"]
+    return IV.flatten()
 
 
 MEMBER1_FIELDS = {

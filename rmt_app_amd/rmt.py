@@ -3,7 +3,8 @@
 result shape ``{"resModel": ..., "comTime": ...}``.
 
 Only the hot path named in BASELINE.json is implemented: ``model == "N2"`` (dynamic homogeneous
-packed-bed reactor).  ``solver-config.ivp`` selects the device integrator: ``"hip-ros4"`` (stiff
+packed-bed reactor), plus the "next" rows of SURVEY.md section 8(f): ``"N1"`` (steady state) and ``"M2"``
+(the dimensional dynamic model).  ``solver-config.ivp`` selects the device integrator: ``"hip-ros4"`` (stiff
 Rosenbrock), ``"hip-rk4"``, ``"hip-rk45"``, ``"AM"`` (the reference's PreCorr3); ``"default"`` - LSODA
 in the reference, pbHomoReactor.py:3576 - and SciPy's stiff method names map to ``"hip-ros4"``.  Any other model id raises - the reference silently returns None there
 (rmtCore.py:90-127), which is not a behaviour worth mirroring for unsupported models.
@@ -38,10 +39,17 @@ def rmtExe(modelInput):
                 from .ensemble import expand_members
                 ensemble = expand_members(modelInput, ensemble)
             resModel = run_n1(modelInput, ensemble)
+        elif modelType == "M2":
+            from .m2 import run_m2
+            ensemble = modelInput['solver-config'].get('ensemble')
+            if ensemble is not None:
+                from .ensemble import expand_members
+                ensemble = expand_members(modelInput, ensemble)
+            resModel = run_m2(modelInput, ensemble)
         else:
             raise NotImplementedError(
-                "model %r is outside the MI355X hot path (only 'N2' and its steady sibling 'N1' are "
-                "built; SURVEY.md section 8)" % (modelType,))
+                "model %r is outside the MI355X hot path (only 'N2', its steady sibling 'N1' and the "
+                "dimensional dynamic model 'M2' are built; SURVEY.md section 8)" % (modelType,))
         tac = timeit.default_timer()
         # the reference's comTime is (timeit.timeit()-timeit.timeit())*1000, i.e. noise
         # (rmt.py:28,67,70); here it is the real wall time in ms.

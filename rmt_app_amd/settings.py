@@ -14,11 +14,12 @@ mean "reference behaviour".
 solverSetting = {
     "N1": {"zNo": 100},
     "N2": {"zNo": 20, "rNo": 5, "tNo": 5, "timesNo": 5},
+    "S2": {"tNo": 10, "zNo": 100, "rNo": 7, "timesNo": 5},        # model M2 (solSetting.py:44-49)
     "T1": {"ode-solver": {"PreCorr3": {"n": 100}}},
 }
 
 MODEL_SETTING = {"GaMaCoTe0": "MAX"}
-PROCESS_SETTING = {"ISO-THER": "iso-thermal"}
+PROCESS_SETTING = {"ISO-THER": "iso-thermal", "NON-ISO-THER": "non-iso-thermal"}
 
 # defaults of the device integrators (not in the reference: it delegates to scipy's defaults)
 DEVICE_DEFAULTS = {

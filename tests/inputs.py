@@ -170,6 +170,47 @@ def dme_script_input(ivp="default", process_type="non-iso-thermal", period=0.5):
     }
 
 
+
+def m2_dme_input(ivp="LSODA", period=10):
+    """PyREMOT/tests/test_rmt_DME.py input (model M2, the dimensional dynamic model:
+    concentrations in kmol/m^3, feed viscosity given, catalyst thermal mass in the energy balance)."""
+    P = 5*1e6
+    T = 523
+    y0_H2O = y0_CH3OH = y0_DME = 0.00001
+    tmf0 = 1 - (y0_H2O + y0_CH3OH + y0_DME)
+    COx = tmf0/(1 + 1)
+    y0_H2 = 1*COx
+    y0_CO2 = 0.5*COx
+    y0_CO = COx - y0_CO2
+    feedMoFr = np.array([y0_H2, y0_CO2, y0_H2O, y0_CO, y0_CH3OH, y0_DME], dtype=np.float32)
+    ct0 = _feed_concentration_rounded(feedMoFr, P, T)          # [kmol/m^3]
+    rea_D, rea_L, bed_por = 0.0381, 1, 0.39
+    cat_d, cat_rho, cat_Cp = 0.002, 1982, 960
+    bulk_rho = cat_rho*(1 - bed_por)
+    SuGaVe = 0.2
+    InGaVe = SuGaVe/bed_por
+    rea_CSA = bed_por*(math.pi*(rea_D**2)/4)
+    VoFlRa = InGaVe*rea_CSA
+    return {
+        "model": "M2",
+        "operating-conditions": {"pressure": P, "temperature": T, "period": period},
+        "feed": {
+            "mole-fraction": 0, "molar-flowrate": 0, "molar-flux": 0,
+            "volumetric-flowrate": VoFlRa,
+            "concentration": ct0,
+            "mixture-viscosity": 1e-5,
+            "components": {"shell": list(DME_COMPONENTS), "tube": [], "medium": []},
+        },
+        "reactions": dict(DME_REACTIONS_SPACED),
+        "reaction-rates": dme_kinetics(bulk_rho),
+        "external-heat": {"OvHeTrCo": 50, "EfHeTrAr": 4/rea_D, "MeTe": 523},
+        "reactor": {
+            "ReInDi": rea_D, "ReLe": rea_L, "PaDi": cat_d, "BeVoFr": bed_por,
+            "CaBeDe": bulk_rho, "CaDe": cat_rho, "CaSpHeCa": cat_Cp/1000,
+        },
+        "solver-config": {"ivp": ivp},
+    }
+
 def ch4_input(ivp="default", period=10):
     """PyREMOT/tests/test_rmt_N2_CH4.py input (3 species, 1 reaction, adiabatic)."""
     P = 3*1e5

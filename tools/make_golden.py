@@ -366,6 +366,112 @@ def g_helpers():
     print("G7 written")
 
 
+# --------------------------------------------------------------------------- G9 (model M2)
+def m2_capture(mi, zNo):
+    """rmtExe(model M2) up to the first solve_ivp call (pbReactor.py:719): IV and the args tuple."""
+    import PyREMOT.docs.pbReactor as PBR
+    box = {}
+
+    def fake(fun, t_span, y0, method=None, t_eval=None, args=None, **kw):
+        box["IV"] = np.array(y0, dtype=float)
+        box["args"] = args
+        box["fun"] = fun
+        raise _Captured()
+
+    PBR.solve_ivp = fake
+    try:
+        with mesh(zNo, model="S2"), quiet():
+            try:
+                rmtExe(mi)
+            except _Captured:
+                pass
+    finally:
+        PBR.solve_ivp = REAL_SOLVE_IVP
+    return box["IV"], box["args"], box["fun"]
+
+
+def m2_states(IV, V, N, seed):
+    """dimensional test states: rows C_i [kmol/m^3], last row T [K]"""
+    rng = np.random.default_rng(seed)
+    Y0 = IV.reshape(V, N)
+    z = np.linspace(0, 1, N)
+    s1 = Y0.copy()
+    for i in range(V - 1):
+        s1[i] = Y0[i]*(1.0 + 0.15*np.sin(2.0*np.pi*(z + 0.1*i))) + 0.003*(i + 1)*z*Y0[0]
+    s1[V - 1] = Y0[V - 1] + 12.0*z + 4.0*np.sin(3*np.pi*z)
+    s2 = np.abs(Y0*(1 + 0.05*rng.standard_normal(Y0.shape))) + 1e-4*rng.random(Y0.shape)*Y0[0]
+    s2[V - 1] = Y0[V - 1] + 15.0*rng.random(N) - 3.0
+    s3 = s1.copy()
+    idx = rng.integers(0, N, size=max(2, N//10))
+    s3[2, idx] = -1e-3*rng.random(len(idx))
+    s3[4, idx[::2]] = 0.0
+    s3[0, idx[1::2]] = -5e-2
+    return [s.flatten() for s in (s1, s2, s3)]
+
+
+def g_m2():
+    out, setup = {}, {}
+    mi = INP.m2_dme_input()
+    for zNo in (20, 100, 1024):
+        IV, args, fun = m2_capture(mi, zNo)
+        rls, rsc, FunParam = args
+        V = FunParam["const"]["varNo"]
+        if zNo == 20:
+            setup = {"const": tolist(FunParam["const"]), "constBC1": tolist(FunParam["constBC1"]),
+                     "ExHe": tolist(FunParam["ExHe"]), "ReSpec": tolist(FunParam["ReSpec"]),
+                     "IV": IV.tolist()}
+        states = [IV] + m2_states(IV, V, zNo, seed=zNo + 2)
+        if zNo == 1024:
+            states = states[:2]
+        Y = np.array(states)
+        t0 = time.time()
+        with quiet():
+            F = np.array([np.array(fun(0.0, y, *args), dtype=float) for y in Y])
+        print("G9 M2 zNo=%d: %d RHS calls in %.1fs" % (zNo, len(Y), time.time() - t0))
+        out["rhs_%d_y" % zNo] = Y
+        out["rhs_%d_f" % zNo] = F
+    # the reference's own RK4 on the M2 RHS (odeSolver.py:17-40), zNo=20, 100 steps of 1e-6 s
+    IV, args, fun = m2_capture(mi, 20)
+    with quiet():
+        traj = ODES.RK4(0.0, 100*1e-6, 100, IV, lambda t, y, p: fun(t, y, *p), args)
+    out["rk4_20_traj"] = np.array(traj, dtype=float)[:, ::10]
+    out["rk4_20_h"] = np.array(1e-6)
+    np.savez_compressed(os.path.join(GOLD, "g9_m2.npz"), **out)
+    with open(os.path.join(GOLD, "g9_m2_setup.json"), "w") as f:
+        json.dump(setup, f, indent=1)
+    print("G9 written")
+
+
+def g_m2_run(zNo=20, tNo=2, rtol=1e-10, atol=1e-13, method="LSODA"):
+    """rmtExe(model M2) end to end with tolerances injected at the solve_ivp call site; the
+    reference returns plot lists only (pbReactor.py:835-840), so the end state of every output
+    interval is recorded at the call site."""
+    import PyREMOT.docs.pbReactor as PBR
+    mi = INP.m2_dme_input(ivp=method)
+    ends, nfev = [], [0]
+
+    def wrapped(fun, t_span, y0, method=None, t_eval=None, args=None, **kw):
+        sol = REAL_SOLVE_IVP(fun, t_span, y0, method=method, t_eval=t_eval, args=args,
+                             rtol=rtol, atol=atol)
+        ends.append((float(t_span[1]), np.array(sol.y[:, -1], dtype=float)))
+        nfev[0] += sol.nfev
+        return sol
+
+    PBR.solve_ivp = wrapped
+    t0 = time.time()
+    try:
+        with mesh(zNo, tNo, model="S2"), quiet():
+            res = rmtExe(mi)
+    finally:
+        PBR.solve_ivp = REAL_SOLVE_IVP
+    np.savez_compressed(os.path.join(GOLD, "g9_m2_tight_%s.npz" % method.lower()),
+                        zNo=zNo, tNo=tNo, rtol=rtol, atol=atol, nfev=nfev[0], wall_s=time.time() - t0,
+                        times=np.array([t for t, _ in ends]), states=np.array([y for _, y in ends]),
+                        last_leg=np.array([d["leg"] for d in res["resModel"]["dataList"]]),
+                        last_y=np.array([d["y"] for d in res["resModel"]["dataList"]], dtype=float))
+    print("G9 M2 tight run: nfev=%d wall=%.0fs" % (nfev[0], time.time() - t0))
+
+
 def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     for what in argv:
@@ -385,6 +491,12 @@ def main(argv):
             g_n1()
         elif what == "helpers":
             g_helpers()
+        elif what == "m2":
+            g_m2()
+        elif what.startswith("m2run"):
+            kw = dict(a.split("=") for a in what.split(":")[1:])
+            g_m2_run(int(kw.get("zNo", 20)), int(kw.get("tNo", 2)), float(kw.get("rtol", 1e-10)),
+                     float(kw.get("atol", 1e-13)), kw.get("method", "LSODA"))
         else:
             raise SystemExit("unknown target " + what)
 

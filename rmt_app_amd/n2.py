@@ -75,6 +75,8 @@ class N2Device:
         self.features = tuple(features)
         for f in self.features:
             self.defines[{"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}[f]] = "1"
+        if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in self.defines and code is None:
+            self.defines["RMT_M2_NEWTON"] = str(plan.m2_newton_sweeps(members, mech, self.N))
         # sweep-invariant member fields become literals (frees SGPRs); a single reactor is NOT
         # specialised by default - every new operating point would cost a 2-3 s JIT
         if specialize is None:

@@ -211,8 +211,8 @@ class Mechanism:
         fit = min(2, (144*1024)//per)
         if want is not None:
             return min(int(want), fit)
-        if not chained and block == 512 and npt == 2 and self.V <= 8 and not fp32:
-            return 0
+        if not chained and block == 512 and npt == 2 and self.V <= 8 and not fp32 and self.model != "M2":
+            return 0          # (M2's node functions need the registers: 47 spilled VGPRs otherwise)
         return fit
 
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
@@ -336,6 +336,22 @@ def member_constants_m2(modelInput, mech, zNo):
     row[F["TM"]] = ExHe['MeTe']
     row[F["CIN"]:F["CIN"] + mech.S] = SpCoi0                          # :1135
     return named, row
+
+
+def m2_newton_sweeps(rows, mech, zNo):
+    """Newton sweeps the M2 pressure march needs (RMT_M2_NEWTON), from the relative pressure drop
+    of the feed state over the bed (largest over the members): the error contracts like
+    e' ~ 0.01..0.05 e^2 starting from e0 = drop, and the kernel accepts a last update < 3e-7."""
+    rows = np.asarray(rows, dtype=float).reshape(-1, MEMBER_FIXED + mech.S)
+    F = MEMBER_FIELDS
+    worst = 0.0
+    for r in rows:
+        c = r[F["CIN"]:F["CIN"] + mech.S]
+        ct = np.sum(c)
+        M = np.dot(c/ct, mech.MW)*1e-3
+        sup, P0 = r[F["RHO_K"]]*ct, r[F["P0"]]
+        worst = max(worst, zNo*(r[F["BETA"]]*sup/P0 + r[F["ALPHA_K"]]*(M*ct)*sup*sup/P0**2)/P0)
+    return 2 if worst < 2e-3 else 3 if worst < 0.12 else 4 if worst < 0.3 else 5
 
 
 def initial_state_m2(named, mech, zNo):

@@ -75,5 +75,6 @@ def run_n1(modelInput, members_inputs=None):
     for p, acc, rej in zip(packs, stats["accepted"], stats["rejected"]):
         p["device-stats"] = {"accepted": int(acc), "rejected": int(rej)}
     if displayResult:
-        print("display-result: plotting of steady-state profiles is outside the device path")
+        from .plotting import plotResultsSteadyState
+        plotResultsSteadyState([packs[0]])                       # pbHomoReactor.py:3011-3013
     return packs if members_inputs else [packs[0]]

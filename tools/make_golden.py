@@ -472,6 +472,67 @@ def g_m2_run(zNo=20, tNo=2, rtol=1e-10, atol=1e-13, method="LSODA"):
     print("G9 M2 tight run: nfev=%d wall=%.0fs" % (nfev[0], time.time() - t0))
 
 
+# --------------------------------------------------------------------------- G10 (plot/export layer)
+def synthetic_respack():
+    """small resPack of the runN2 schema (pbHomoReactor.py:3664-3696); deterministic numbers"""
+    S, N, tNo = 3, 6, 5
+    xs = np.linspace(0, 1, N)
+    packs = []
+    for k in range(tNo):
+        ys = np.array([[0.1*(i + 1) + 0.01*k + 0.001*j for j in range(N)] for i in range(S)] +
+                      [[500.0 + k + 0.5*j for j in range(N)]])
+        packs.append({"modelId": "N2", "processType": "non-iso-thermal", "successStatus": True,
+                      "dataShape": (S + 1, N), "labelList": ["A", "B", "C", "Temperature"],
+                      "indexList": [S, S + 1, S], "dataTime": 0.1*(k + 1), "dataXs": xs, "dataYs": ys})
+    return {"computation-time": 1.234, "dataPack": packs}, tNo
+
+
+def g_plot():
+    import tempfile
+    import PyREMOT.solvers.solResultAnalysis as SRA
+    from PyREMOT.core.utilities import selectRandomForList, selectFromListByIndex
+    from PyREMOT.library.saveResult import saveResultClass as sRes
+    out = {"picks": {}}
+    for seed in (0, 1, 7, 1234):
+        np.random.seed(seed)
+        out["picks"][str(seed)] = [int(v) for v in selectRandomForList(list(range(5)), 2)]
+    np.random.seed(3)
+    out["picks10"] = [int(v) for v in selectRandomForList(list(range(10)), 2)]
+    out["select"] = [selectFromListByIndex([], [1, 2, 3]), selectFromListByIndex([2, 0], [1, 2, 3])]
+    figs = []
+    real = SRA.pltc.plots2D
+    SRA.pltc.plots2D = staticmethod(lambda data, xLabel, yLabel, title="": figs.append(
+        {"title": title, "xlabel": xLabel, "ylabel": yLabel,
+         "lines": [{"leg": d["leg"], "x": tolist(d["x"]), "y": tolist(d["y"])} for d in
+                   (data if isinstance(data, list) else [data])]}))
+    try:
+        resPack, tNo = synthetic_respack()
+        np.random.seed(11)
+        SRA.plotResultsDynamic(resPack, tNo)
+        out["dynamic"] = list(figs)
+        figs.clear()
+        d = dict(resPack["dataPack"][0])
+        d.update({"modelId": "N1", "computation-time": 0.5, "labelList": ["A", "B", "C", "Pressure", "Temperature"],
+                  "indexList": [3, 3, 4], "dataYs": np.vstack([d["dataYs"][:3], np.linspace(50, 49, 6), d["dataYs"][3:]])})
+        SRA.plotResultsSteadyState([d])
+        out["steady"] = list(figs)
+    finally:
+        SRA.pltc.plots2D = real
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            sRes.saveListToText([1.5, "abc", [1, 2], np.float64(2.25)])
+            sRes.saveListToCSV([[1, 2.5, "x"], [3, 4.0, "y,z"]], ["a", "b", "c"])
+            out["txt"] = open("saveFile.txt", newline="").read()
+            out["csv"] = open("saveFile.csv", newline="").read()
+        finally:
+            os.chdir(cwd)
+    with open(os.path.join(GOLD, "g10_plot_export.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("G10 written")
+
+
 def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     for what in argv:
@@ -491,6 +552,8 @@ def main(argv):
             g_n1()
         elif what == "helpers":
             g_helpers()
+        elif what == "plot":
+            g_plot()
         elif what == "m2":
             g_m2()
         elif what.startswith("m2run"):

@@ -441,8 +441,9 @@ class Lowered:
                 bop, ba, bb = g.nodes[b]
                 if bop in NEGEXP and only_divides(b):
                     new[i] = mul(new[a], g2._mk(NEGEXP[bop], new[ba].i))
-                elif bop == "powi" and new[b] is None:
-                    r = g2._mk("rcp", new[ba].i)
+                elif bop == "powi" and (new[b] is None or (bb > 0 and div_uses.get(ba, 0) >= 2
+                                                           and not g.is_const(ba))):
+                    r = g2._mk("rcp", new[ba].i)          # 1/y exists anyway: x/y^n = x*(1/y)^n
                     new[i] = mul(new[a], g2._mk("powi", r.i, bb))
                 elif div_uses.get(b, 0) >= 2 and not g.is_const(b):
                     new[i] = mul(new[a], g2._mk("rcp", new[b].i))
@@ -458,6 +459,83 @@ class Lowered:
             else:
                 x, y = new[a].i, new[b].i
                 if op in ("add", "mul", "min", "max") and x > y:
+                    x, y = y, x
+                new[i] = g2._mk(op, x, y)
+        return Lowered(g2, [new[o].i for o in self.outputs], self.S).reassociate()
+
+    def reassociate(self):
+        """Products only: flatten every multiplication tree whose inner products have no other
+        user, fold ALL its constant factors into one, drop factors 1.0, and rebuild it as
+        ((K * inputs...) * others...) so that sub-products such as 1e-5*P are shared between the
+        species (hash-consing).  Changes rounding at the 1e-16 level, never the exception
+        behaviour (Python's float product does not raise)."""
+        g = self.g
+        nuse = {}
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op in ("const", "in"):
+                continue
+            nuse[a] = nuse.get(a, 0) + 1
+            if b is not None and op != "powi":
+                nuse[b] = nuse.get(b, 0) + 1
+        for o in self.outputs:
+            nuse[o] = nuse.get(o, 0) + 1
+
+        def factors(i, root):
+            op, a, b = g.nodes[i]
+            if op == "mul" and (root or nuse.get(i, 0) == 1):
+                return factors(a, False) + factors(b, False)
+            return [i]
+
+        inner = set()        # mul nodes absorbed into a parent product
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op == "mul":
+                for c in (a, b):
+                    if g.nodes[c][0] == "mul" and nuse.get(c, 0) == 1:
+                        inner.add(c)
+        g2 = Graph()
+        new = {}
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op == "const":
+                new[i] = g2.const(g.cval(i))
+            elif op == "in":
+                new[i] = g2.inp(a)
+            elif op == "mul":
+                if i in inner:
+                    continue
+                fs = factors(i, True)
+                K, rest = 1.0, []
+                for f in fs:
+                    if g.is_const(f):
+                        K *= g.cval(f)
+                    else:
+                        rest.append(f)
+                if not math.isfinite(K) or K == 0.0 or not rest:
+                    x, y = new[a].i if a in new else None, new[b].i if b in new else None
+                    if x is None or y is None:        # operands were absorbed: rebuild plainly
+                        acc = None
+                        for f in fs:
+                            acc = new[f] if acc is None else acc._bin("mul", acc, new[f], lambda p, q: p*q)
+                        new[i] = acc
+                    else:
+                        new[i] = g2._mk("mul", min(x, y), max(x, y))
+                    continue
+                ins = sorted([f for f in rest if g.nodes[f][0] == "in"], key=lambda f: g.nodes[f][1])
+                oth = [f for f in rest if g.nodes[f][0] != "in"]
+                order = ins + oth
+                acc = None if K == 1.0 else g2.const(K)
+                for f in order:
+                    acc = new[f] if acc is None else acc._bin("mul", acc, new[f], lambda p, q: p*q)
+                new[i] = acc
+            elif op == "powi":
+                new[i] = g2._mk("powi", new[a].i, b)
+            elif b is None:
+                new[i] = g2._mk(op, new[a].i)
+            else:
+                x, y = new[a].i, new[b].i
+                if op in ("add", "min", "max") and x > y:
                     x, y = y, x
                 new[i] = g2._mk(op, x, y)
         return Lowered(g2, [new[o].i for o in self.outputs], self.S)

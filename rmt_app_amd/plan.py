@@ -203,12 +203,13 @@ class Mechanism:
 
     def lds_state(self, fp32, block, npt, want=None, chained=False):
         """How many of the two long-lived RK4 vectors (y_n, K accumulator) the on-chip stepper
-        keeps in LDS instead of VGPRs.  Default: as many as fit in 144 KiB of the CU's 160 KiB,
+        keeps in LDS instead of VGPRs.  Default: as many as fit in 126 KiB of the CU's 160 KiB
+        (16 KiB go to the exp table, the rest to the scan/hand-over buffers),
         except for the single-workgroup kernel at 512 threads x 2 nodes with V <= 8, whose 249
         VGPRs hold everything without scratch (measured 12.3 vs 11.9 G node-steps/s); the chained
         kernel always prefers LDS (6.4 vs 3.4)."""
         per = self.V*block*npt*(4 if fp32 else 8)
-        fit = min(2, (144*1024)//per)
+        fit = min(2, (126*1024)//per)
         if want is not None:
             return min(int(want), fit)
         if not chained and block == 512 and npt == 2 and self.V <= 8 and not fp32 and self.model != "M2":

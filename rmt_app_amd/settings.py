@@ -28,10 +28,11 @@ DEVICE_DEFAULTS = {
     "rk45-h0": 1e-6,
     "rk45-max-steps": 50_000_000,
     "rk4-dt": 2e-6,
-    # measured (tools/ros4_tol_scan.py): at 3e-7 every outlet value of both reference DME inputs is
-    # within 2e-8 of the tight SciPy run at all five output times; at 1e-6 single values reach 1.4e-6
-    "ros4-rtol": 3e-7,
-    "ros4-atol": 3e-10,
+    # measured (tools/ros4_tol_scan.py, profiles/round1_time_to_solution.md): the outlet error against
+    # the tight SciPy run is usually ~5e-9 but single output times reach the local tolerance level
+    # (1.4e-6 at rtol 1e-6, 3.9e-7 at 3e-7, <= 8e-8 at 1e-7): 1e-7 keeps the 1e-6 requirement with margin
+    "ros4-rtol": 1e-7,
+    "ros4-atol": 1e-10,
     "ros4-h0": 1e-5,
     "n1-rtol": 1e-8,     # the steady profile is one lane's worth of work: afford tight defaults
     "n1-atol": 1e-11,

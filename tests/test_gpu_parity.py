@@ -390,7 +390,7 @@ def test_rmtexe_ros4_end_to_end_vs_tight_scipy_reference(name):
     outlet mole fractions and temperature <= 1e-6 vs the reference under LSODA rtol 1e-10."""
     g = np.load(os.path.join(G, "g4_tight_%s_lsoda.npz" % name))
     mi = INP.ALL_N2_INPUTS[name](ivp="hip-ros4")
-    mi["solver-config"].update({"quiet": True})          # default tolerances (3e-7 / 3e-10)
+    mi["solver-config"].update({"quiet": True})          # default tolerances (1e-7 / 1e-10)
     res = rmtExe(mi)
     dp = res["resModel"]["dataPack"]
     worst = 0.0

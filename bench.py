@@ -137,8 +137,8 @@ def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--members", type=int, default=MEMBERS_PER_GPU, help="reactors per GPU")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu-baseline", action="store_true")

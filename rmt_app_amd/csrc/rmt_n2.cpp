@@ -339,9 +339,9 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
     if (!h || !y || !stats) return fail("null argument");
     if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad ros4 arguments");
     if (!h->f_ros4) return fail("code object has no ros4 kernel");
-    if (h->block > 256)
+    if (h->block > 512)
         return fail("the Rosenbrock kernel holds a VxV matrix per lane: generate the code object with "
-                    "block <= 256 (got %d)", h->block);
+                    "block <= 512 (got %d)", h->block);
     // 7 vector arrays + the VxV inverse per node (= V more "vector arrays")
     if (ensure_work(h, 8 + (size_t)h->V)) return 1;   // 7 stage arrays + VxV inverses + upwind coupling (model M2)
     const size_t nmask = (size_t)h->E * h->N;

@@ -324,3 +324,28 @@ def test_generated_n1_node_function_vs_reference(template):
         # k = 2 is the outlet state, close to chemical equilibrium: the rates are differences of
         # nearly equal forward/backward terms there (same conditioning issue as tests/parity.py)
         assert relerr(out[k], F[k]) < (1e-11 if k < 2 else 1e-7), (k, out[k], F[k])
+
+
+def test_benchmark_mesh_golden_g8_vs_emulated_rk4(template):
+    """Golden G8 (SciPy DOP853, rtol 1e-10, on the oracle's vectorised RHS at zNo = 1024;
+    tools/make_mesh_golden.py) cross-checked on the CPU by an independent integration: the host
+    build of the generated kernel source under the reference's RK4 at dt = 2e-6 s, 50 000 steps to
+    the first output time t = 0.1 s (about 20 s on one core)."""
+    p = os.path.join(G, "g8_mesh1024_dme_nb_dop853.npz")
+    if not os.path.exists(p):
+        pytest.skip("golden G8 not generated")
+    g = np.load(p)
+    assert int(g["zNo"]) == 1024 and str(g["method"]) == "DOP853" and float(g["rtol"]) <= 1e-10
+    assert int(g["done"]) == len(g["times"]) == g["states"].shape[0] and g["states"].shape[1] == 7*1024
+    pr = O.setup_n2(INP.dme_notebook_input(), 1024)
+    for k in range(int(g["done"])):          # physical profiles
+        pk = O.pack_interval(g["states"][k], pr, float(g["times"][k]))
+        assert np.allclose(np.sum(pk["dataYs"][:6], axis=0), 1.0, atol=1e-12)
+        assert 520.0 < pk["dataYs"][6].min() and pk["dataYs"][6].max() < 700.0
+    mi = INP.dme_notebook_input()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, 1024)
+    emu = HostEmu(mech.source(template), tag="dme_nb")
+    y, flags = emu.rk4(plan.initial_state(nm, mech, 1024), row, 1024, 2e-6, 50000)
+    assert not flags.any()
+    assert rowwise_err(y[0], g["states"][0], 7) < 1e-7

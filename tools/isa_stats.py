@@ -11,8 +11,9 @@ block, npt = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((2, 512)
 lds = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4].lstrip("-").isdigit() else None
 kern = sys.argv[5] if len(sys.argv) > 5 else "rmt_n2_rk4_reg"
 defines = dict(a.split("=", 1) for a in sys.argv[6:])
+copt = defines.pop("COPT", "")
 mech = plan.Mechanism(INP.m2_dme_input() if name == "m2" else INP.ALL_N2_INPUTS[name]())
-blob, _ = hipbind.compile_source(mech.source(hipbind.kernel_template(), False, block, npt, lds, defines))
+blob, _ = hipbind.compile_source(mech.source(hipbind.kernel_template(), False, block, npt, lds, defines), "gfx950", copt)
 f = tempfile.NamedTemporaryFile(suffix=".hsaco", delete=False); f.write(blob); f.close()
 out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", f.name], capture_output=True, text=True).stdout
 i = out.index("<%s>:" % kern)

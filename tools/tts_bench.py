@@ -13,6 +13,8 @@ from rmt_app_amd.n2 import N2Device
 
 DEFS = dict(a.split("=", 1) for a in sys.argv[4:])
 SKIP_RK4 = bool(DEFS.pop("SKIP_RK4", ""))
+ROS_BLOCK = int(DEFS.pop("ROS_BLOCK", 256))
+RTOLS = [float(v) for v in DEFS.pop("RTOLS", "1e-5,1e-6,1e-7").split(",")]
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 T_END = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
@@ -31,8 +33,8 @@ assert not dev.status().any()
 ref = y.cpu().numpy().reshape(E, mech.V, N)[:, :, -1]
 print("| hip-rk4 dt=2e-6 | %d | %d | %g | %d | %.3f | - |" % (E, N, T_END, n, w), flush=True)
 dev.close()
-for rtol in (1e-5, 1e-6, 1e-7):
-    dev = N2Device(mech, rows, N, block=256, npt=1, defines=DEFS, features=("ros4",))
+for rtol in RTOLS:
+    dev = N2Device(mech, rows, N, block=ROS_BLOCK, npt=1, defines=DEFS, features=("ros4",))
     y = dev.to_device(IV)
     t0 = time.perf_counter(); dev.ros4(y, 0.0, T_END, rtol, 1e-3*rtol, 1e-5, 10**7); torch.cuda.synchronize(); w = time.perf_counter() - t0
     fl = dev.status(); st = dev.rk45_stats()

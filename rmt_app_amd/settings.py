@@ -28,11 +28,11 @@ DEVICE_DEFAULTS = {
     "rk45-h0": 1e-6,
     "rk45-max-steps": 50_000_000,
     "rk4-dt": 2e-6,
-    # measured (tools/ros4_tol_scan.py, profiles/round1_time_to_solution.md): the outlet error against
-    # the tight SciPy run is usually ~5e-9 but single output times reach the local tolerance level
-    # (1.4e-6 at rtol 1e-6, 3.9e-7 at 3e-7, <= 8e-8 at 1e-7): 1e-7 keeps the 1e-6 requirement with margin
-    "ros4-rtol": 1e-7,
-    "ros4-atol": 1e-10,
+    # RODAS4 (tools/ros4_tol_scan.py, profiles/round1_ros_scheme.md): the outlet error against the tight
+    # SciPy run falls smoothly with the tolerance - 4.5e-7 at rtol 1e-5, 1.1e-7 at 1e-6, 4e-8 at 1e-7 -
+    # so 1e-6 keeps the 1e-6 requirement with a factor 9 in hand (the Kaps-Rentrop pair needed 1e-7)
+    "ros4-rtol": 1e-6,
+    "ros4-atol": 1e-9,
     "ros4-h0": 1e-5,
     "n1-rtol": 1e-8,     # the steady profile is one lane's worth of work: afford tight defaults
     "n1-atol": 1e-11,

@@ -390,7 +390,7 @@ def test_rmtexe_ros4_end_to_end_vs_tight_scipy_reference(name):
     outlet mole fractions and temperature <= 1e-6 vs the reference under LSODA rtol 1e-10."""
     g = np.load(os.path.join(G, "g4_tight_%s_lsoda.npz" % name))
     mi = INP.ALL_N2_INPUTS[name](ivp="hip-ros4")
-    mi["solver-config"].update({"quiet": True})          # default tolerances (1e-7 / 1e-10)
+    mi["solver-config"].update({"quiet": True})          # default tolerances (1e-6 / 1e-9)
     res = rmtExe(mi)
     dp = res["resModel"]["dataPack"]
     worst = 0.0
@@ -399,7 +399,7 @@ def test_rmtexe_ros4_end_to_end_vs_tight_scipy_reference(name):
         worst = max(worst, np.max(np.abs(a - b)/np.abs(b)))
     assert worst < 2e-7, worst                           # requirement: 1e-6
     st = res["resModel"]["device-stats"]
-    assert 200 < st["steps"] < 3000, st
+    assert 100 < st["steps"] < 3000, st
 
 
 def test_ros4_1024_nodes_ensemble_matches_explicit():
@@ -616,12 +616,14 @@ def _g8():
     return np.load(p)
 
 
-@pytest.mark.parametrize("ivp,tol", [("hip-rk4", 1e-7), ("hip-ros4", 1e-6)])
+@pytest.mark.parametrize("ivp,tol", [("hip-rk4", 1e-7), ("hip-ros4", 3e-6)])
 def test_benchmark_mesh_1024_vs_scipy_on_oracle_rhs(ivp, tol):
     """at the benchmark mesh (zNo = 1024) the reference's own RHS is
     infeasible, so the trajectory is pinned by SciPy DOP853 (rtol 1e-10) driving the oracle's
     vectorised RHS (tools/make_mesh_golden.py, golden G8; that RHS is pinned <= 1e-12 against the
-    reference at this N by G2).  Whole profiles of mole fractions and temperature, every output time."""
+    reference at this N by G2).  Whole profiles at every output time, default tolerances:
+    BASELINE's metric max|dMoFri| (absolute) and |dT|/T <= 1e-6; relative to each value (trace
+    species and the steep front included) <= `tol`; outlet values <= 1e-6 relative."""
     g = _g8()
     done = int(g["done"])
     mi = INP.dme_notebook_input(ivp=ivp)
@@ -631,5 +633,8 @@ def test_benchmark_mesh_1024_vs_scipy_on_oracle_rhs(ivp, tol):
     for k in range(done):
         ref = O.pack_interval(g["states"][k], pr, float(g["times"][k]))["dataYs"]
         got = dp[k]["dataYs"]
-        err = np.max(np.abs(got - ref)/np.maximum(np.abs(ref), 1e-30))
-        assert err < tol, (k, err)
+        assert np.max(np.abs(got[:6] - ref[:6])) < 1e-6, k                     # max |dMoFri|
+        assert np.max(np.abs(got[6] - ref[6])/ref[6]) < 1e-6, k               # |dT|/T
+        rel = np.abs(got - ref)/np.maximum(np.abs(ref), 1e-30)
+        assert np.max(rel) < tol, (k, np.max(rel))
+        assert np.max(rel[:, -1]) < 1e-6, (k, np.max(rel[:, -1]))

@@ -99,7 +99,7 @@ out["accuracy_vs_tight_reference"] = acc
 devr = N2Device(mech, rows, N, block=256, npt=1, features=("ros4",))
 y = devr.to_device(IV)
 t0 = time.perf_counter()
-devr.ros4(y, 0.0, 10.0, 1e-7, 1e-10, 1e-5, 10**7)
+devr.ros4(y, 0.0, 10.0, 1e-6, 1e-9, 1e-5, 10**7)
 torch.cuda.synchronize()
 w = time.perf_counter() - t0
 st = devr.rk45_stats()

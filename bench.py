@@ -4,8 +4,10 @@
 Workload (config.workload): BASELINE configs[1]'s reactor - the TEST2.ipynb DME case (6 species,
 3 reactions, fp64) on 1024 axial nodes, classic RK4 with dt = 2e-6 s (the stable step for this case) - replicated as the
 per-GPU shard of configs[3]'s ensemble: 256 independent reactors per GPU with the inlet-T /
-pressure sweep of SURVEY.md section 8(d).4 (2048 members at 8 GPUs).  One "step" = one RK4 time
-step (4 RHS evaluations) of every node of every member on this rank.  Ranks are independent
+pressure sweep of SURVEY.md section 8(d).4 (2048 members at 8 GPUs).  One bench "step" = one
+output interval of the reference's time loop (pbHomoReactor.py:3589-3690) = ONE device launch of
+1000 RK4 time steps (4 RHS evaluations each) of every node of every member on this rank; the metric
+counts RK4 steps: value = ranks x members x nodes x steps x 1000 / time.  Ranks are independent
 (weak scaling, no data-path collective): rank 0 broadcasts the packed constants once (RCCL),
 outlet rows are gathered at the end.
 
@@ -28,6 +30,7 @@ FP64_OPS_PER_NODE_STEP = 1632   # v_*_f64 instructions per node per RK4 step in 
 N_NODES = 1024
 MEMBERS_PER_GPU = 256
 DT = 2e-6
+RK4_PER_STEP = 1000          # one bench "step" = one output interval = ONE launch of 1000 RK4 steps (2 ms of reactor time)
 
 
 def sweep_member_inputs(first, count, total=2048):
@@ -137,8 +140,9 @@ def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=10,
+                    help="timed bench steps; one step = one launch of %d RK4 steps of every reactor" % RK4_PER_STEP)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--members", type=int, default=MEMBERS_PER_GPU, help="reactors per GPU")
     ap.add_argument("--nodes", type=int, default=N_NODES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,10 +199,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    dev.rk4(y, DT, args.warmup)
+    for _ in range(args.warmup):
+        dev.rk4(y, DT, RK4_PER_STEP)
     barrier()
     t0 = time.perf_counter()
-    dev.rk4(y, DT, args.steps)
+    for _ in range(args.steps):               # back-to-back launches on one stream, no host sync in between
+        dev.rk4(y, DT, RK4_PER_STEP)
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = dev.last_kernel_ms()
@@ -215,17 +221,20 @@ def main():
 
     dev.close()
     if rank == 0:
-        node_steps = world*E*n_nodes*args.steps
+        node_steps = world*E*n_nodes*args.steps*RK4_PER_STEP
         value = node_steps/tmax
         bytes_per_node_step = 2*(mech.S + 2)*8
-        achieved = (E*n_nodes*args.steps*bytes_per_node_step/1e9)/(kernel_ms/1e3)
+        # kernel_ms = the LAST launch (HIP events on the launch stream): RK4_PER_STEP RK4 steps
+        achieved = (E*n_nodes*RK4_PER_STEP*bytes_per_node_step/1e9)/(kernel_ms/1e3)
         line = {
             "metric": "mesh-node-steps/s (6-sp DME dynamic model)",
             "value": value, "unit": "mesh-node-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3*tmax/args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "DME N2 (TEST2.ipynb reactor), %d nodes, RK4 dt=2e-6 s, %d "
-                                   "reactors/GPU of the 64x32 inlet-T/P sweep" % (n_nodes, E),
+                                   "reactors/GPU of the 64x32 inlet-T/P sweep; one step = one output interval "
+                                   "= one launch of %d RK4 steps" % (n_nodes, E, RK4_PER_STEP),
+                       "rk4_steps_per_step": RK4_PER_STEP,
                        "members_per_gpu": E, "nodes": n_nodes, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,
                        "kernel": "rmt_n2_rk4_%s block=%d npt=%d lds_state=%d" % (
@@ -245,15 +254,15 @@ def main():
             # the real ceiling of this kernel: fp64 vector issue (78.6 TFLOP/s spec = 39.3e12 fp64
             # lane-instructions/s); ops/node-step is the static count in the kernel's ISA
             "valu_fp64": {"ops_per_node_step": FP64_OPS_PER_NODE_STEP,
-                          "achieved_Tops": E*n_nodes*args.steps*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/1e12,
+                          "achieved_Tops": E*n_nodes*RK4_PER_STEP*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/1e12,
                           "peak_Tops": 39.3,
-                          "frac": E*n_nodes*args.steps*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/39.3e12},
+                          "frac": E*n_nodes*RK4_PER_STEP*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/39.3e12},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)
             line["accuracy"] = accuracy_vs_scipy_reference()
             line["time_to_solution"] = time_to_solution(mech, rows, IV, n_nodes)
-            line["time_to_solution"]["rk4_equivalent_wall_s"] = round(250000*tmax/args.steps, 3)
+            line["time_to_solution"]["rk4_equivalent_wall_s"] = round(250000*tmax/(args.steps*RK4_PER_STEP), 3)
         print(json.dumps(line))
     if distributed:
         dist.barrier()

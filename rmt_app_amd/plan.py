@@ -152,7 +152,10 @@ class Mechanism:
             "#define RMT_NPT %d" % npt,
             "#define RMT_LDS_STATE %d" % self.lds_state(fp32, block, npt, lds_state),
             "#define RMT_LDS_STATE_CHAIN %d" % self.lds_state(fp32, block, npt, lds_state, chained=True),
-        ] + ["#define %s %s" % (k, v) for k, v in sorted((defines or {}).items())] + [
+        ] + ([] if (block > 64 or "RMT_EXP_BITS" in (defines or {})) else [
+            # one-wave workgroups (small meshes, big ensembles): the 16 KiB exp table would cap the CU
+            # at 9 resident waves (measured -30 % at N=20, E=2048); they keep the 64-entry table
+            "#define RMT_EXP_BITS 6"]) + ["#define %s %s" % (k, v) for k, v in sorted((defines or {}).items())] + [
             "typedef %s real;" % ("float" if fp32 else "double"),
             "__device__ static const real RMT_MW[RMT_S] = %s;" % arr(self.MW),
             "__device__ static const real RMT_DH25[RMT_R] = %s;" % arr(self.StHeRe25),

@@ -531,6 +531,16 @@ class Lowered:
                 new[i] = acc
             elif op == "powi":
                 new[i] = g2._mk("powi", new[a].i, b)
+            elif op == "rcp" and g2.nodes[new[a].i][0] == "mul":
+                # 1/(K*T) -> (1/K)*(1/T): the kernel hands 1/T to the kinetics for free (it needs it
+                # for M/T anyway), so this reciprocal becomes one multiplication
+                mo, ma, mb = g2.nodes[new[a].i]
+                kk, xx = (ma, mb) if g2.is_const(ma) else (mb, ma)
+                if g2.is_const(kk) and g2.nodes[xx] == ("in", "T", None) and g2.cval(kk) != 0.0:
+                    rt = g2._mk("rcp", xx)
+                    new[i] = rt._bin("mul", g2.const(1.0/g2.cval(kk)), rt, lambda p, q: p*q)
+                else:
+                    new[i] = g2._mk(op, new[a].i)
             elif b is None:
                 new[i] = g2._mk(op, new[a].i)
             else:
@@ -578,7 +588,7 @@ class Lowered:
                 e = "rmt_div(%s, %s)" % (A, B)
             elif op == "rcp":
                 pre.append("RMT_CHECK_DEN(flag, %s);" % A)
-                e = "rmt_rcp(%s)" % A
+                e = "invT" if A == "T" else "rmt_rcp(%s)" % A     # 1/T comes with the node state
             elif op == "expn":      # stands for 1/exp(A): Python raises if exp(A) overflows or is 0
                 pre.append("RMT_CHECK_EXP(flag, rmt_abs(%s));" % A)
                 e = "rmt_exp(-%s)" % A
@@ -647,8 +657,9 @@ class Lowered:
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
         return (
             "template <typename FL>\n"
-            "__device__ __forceinline__ void %s(const real T, const real P, const real* __restrict__ x,\n"
-            "        const real* __restrict__ C, real* __restrict__ r, FL& flag) {\n%s\n%s\n}\n"
+            "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
+            "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r, FL& flag) {\n"
+            "    (void)invT;\n%s\n%s\n}\n"
             % (fname, body, outs))
 
 

@@ -184,15 +184,18 @@ class Mechanism:
             lines.append("    d[%d] = %s;" % (k, lincomb(self.nu[k, :], "c")))
         lines.append("}")
         lines.append("__device__ __forceinline__ real rmt_cp_mean(const int i, const real T) {")
-        lines.append("    const real T2 = T * T;")
+        # (Cp(Tref) + a + b T + c T^2 + d T^3)/2 (rmtThermo.py:52-75) in Horner form with the 1/2 and
+        # Cp(Tref) folded into the coefficients: 3 fma per species
         for i in range(S):
             a, b, c, d = (float(v) for v in self.cp_coeff[i])
-            e = "real(%r) + real(%r) * T" % (a, b)
-            if c != 0.0:
-                e += " + real(%r) * T2" % c
+            k0, k1, k2, k3 = 0.5*(float(self.cp_ref[i]) + a), 0.5*b, 0.5*c, 0.5*d
             if d != 0.0:
-                e += " + real(%r) * (T2 * T)" % d
-            lines.append("    if (i == %d) return (real(%r) + (%s)) * real(0.5);" % (i, float(self.cp_ref[i]), e))
+                e = "((real(%r) * T + real(%r)) * T + real(%r)) * T + real(%r)" % (k3, k2, k1, k0)
+            elif c != 0.0:
+                e = "(real(%r) * T + real(%r)) * T + real(%r)" % (k2, k1, k0)
+            else:
+                e = "real(%r) * T + real(%r)" % (k1, k0)
+            lines.append("    if (i == %d) return %s;" % (i, e))
         lines.append("    return real(0);")
         lines.append("}")
         return "\n".join(lines) + "\n"

@@ -364,18 +364,20 @@ def test_chained_workgroups_agree_with_oracle(N, E, block, npt):
     dev.close()
 
 
-def test_ros4_vs_oracle_controller():
-    """Stiff Rosenbrock(4,3) with per-reactor step control vs the oracle's restatement (exact
-    bidiagonal solves there, Jacobi sweeps to 1e-12 here): same step history, same end state."""
+@pytest.mark.parametrize("scheme,defines", [("rodas4", {}), ("kr4", {"RMT_ROS_SCHEME": 0})])
+def test_ros4_vs_oracle_controller(scheme, defines):
+    """Stiff Rosenbrock stepper with per-reactor step control vs the oracle's restatement (exact
+    bidiagonal solves there, Jacobi sweeps here): same step history, same end state - for the
+    default RODAS4 and for the Kaps-Rentrop pair (RMT_ROS_SCHEME 0)."""
     N = 20
-    mi, mech, nm, dev = make_device("dme_script", N, block=64, npt=1, features=("ros4",))
+    mi, mech, nm, dev = make_device("dme_script", N, block=64, npt=1, features=("ros4",), defines=defines)
     y = dev.to_device(plan.initial_state(nm, mech, N))
     rtol, atol, h0, t1 = 1e-6, 1e-9, 1e-5, 0.1
     dev.ros4(y, 0.0, t1, rtol, atol, h0, 10**6)
     assert not dev.status().any()
     st = dev.rk45_stats()
     pr = O.setup_n2(mi, N)
-    want, ost = O.ros4(pr, pr["IV"], 0.0, t1, rtol, atol, h0)
+    want, ost = O.ros4(pr, pr["IV"], 0.0, t1, rtol, atol, h0, scheme=scheme)
     assert st["t_end"][0] == t1
     assert abs(int(st["accepted"][0]) - ost["accepted"]) <= max(3, 0.03*ost["accepted"])
     got = y.cpu().numpy()[0]

@@ -218,8 +218,9 @@ class Mechanism:
         fit = min(2, (126*1024)//per)
         if want is not None:
             return min(int(want), fit)
-        if not chained and block == 512 and npt == 2 and self.V <= 8 and not fp32 and self.model != "M2":
-            return 0          # (M2's node functions need the registers: 47 spilled VGPRs otherwise)
+        if not chained and block == 512 and npt == 2 and self.V <= 8 and not fp32:
+            return 1 if self.model == "M2" else 0      # (M2's node functions need more registers: 13.7 / 13.4 / 11.8 G
+            #                                              node-steps/s with 1 / 2 / 0 vectors in LDS)
         return fit
 
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):

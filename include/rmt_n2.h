@@ -24,12 +24,16 @@
  *                         at pbHomoReactor.py:3609-3610, restricted to an explicit embedded pair
  *                         (Dormand-Prince 5(4)) with per-reactor step control.
  *   rmt_n2_ros4         - the same solve_ivp call site with a STIFF method (the reference's default is
- *                         LSODA, pbHomoReactor.py:3576): linearly-implicit 4th-order Rosenbrock
- *                         (Kaps-Rentrop/Shampine) with embedded error estimate and per-reactor
- *                         step control; SURVEY.md section 8(f) rank 2.
+ *                         LSODA, pbHomoReactor.py:3576): linearly-implicit Rosenbrock method RODAS4
+ *                         (6 stages, order 4(3), L-stable; Hairer & Wanner) with per-reactor step
+ *                         control; SURVEY.md section 8(f) rank 2.  Also integrates model M2
+ *                         (pbReactor.py:719) when the code object was generated for it.
  *   rmt_n1_profile      - PackedBedHomoReactorClass.runN1 / modelEquationN1 (pbHomoReactor.py:2694-3314):
  *                         the steady-state model N1, integrated along z* for E reactors at once
  *                         (one per lane) with the same Rosenbrock scheme; SURVEY.md 8(f) rank 1.
+ *   (model M2)          - PackedBedReactorClass.runM2 / modelEquationM2 (pbReactor.py:552-1165) uses the
+ *                         SAME entry points: the generated prelude selects its node functions
+ *                         (RMT_MODEL 2), state rows are kmol/m^3 and K; SURVEY.md 8(f) rank 3.
  *   rmt_n2_status       - the exceptions Python raises inside the user lambdas / `raise` at
  *                         pbHomoReactor.py:3614-3626, as per-reactor flag words.
  *

@@ -113,11 +113,13 @@ class DistributedEnsemble:
         self.counts = [shard(self.n_total, self.world, r)[1] - shard(self.n_total, self.world, r)[0]
                        for r in range(self.world)]
         mine = member_inputs[self.lo:self.hi]
-        pairs = [plan.member_constants(mi, mech, zNo) for mi in mine]
+        m2 = getattr(mech, "model", "N2") == "M2"          # same row layout, different meanings (plan.py)
+        pack, init = ((plan.member_constants_m2, plan.initial_state_m2) if m2
+                      else (plan.member_constants, plan.initial_state))
+        pairs = [pack(mi, mech, zNo) for mi in mine]
         self.named = [nm for nm, _ in pairs]
         self.rows = np.array([r for _, r in pairs]).reshape(len(mine), plan.MEMBER_FIXED + mech.S)
-        self.IV = np.array([plan.initial_state(nm, mech, zNo) for nm in self.named]).reshape(
-            len(mine), mech.V*zNo)
+        self.IV = np.array([init(nm, mech, zNo) for nm in self.named]).reshape(len(mine), mech.V*zNo)
         # member fields that are identical over the WHOLE ensemble become kernel literals: agree on
         # them across ranks (rank 0's values; a column counts only if every rank finds it uniform
         # and equal to rank 0's)

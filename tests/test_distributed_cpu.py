@@ -25,17 +25,17 @@ def _free_port():
     return p
 
 
-def _members(n):
-    base = INP.dme_notebook_input()
+def _members(n, model="N2"):
+    base = INP.dme_notebook_input() if model == "N2" else INP.m2_dme_input()
     return ENS.expand_members(base, {"temperature": np.linspace(513, 533, n), "pressure": [5.0e6]})
 
 
-def _worker(rank, world, port, n_members, N, out_path):
+def _worker(rank, world, port, n_members, N, out_path, model="N2"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle.hostemu import HostEmu
-        members = _members(n_members)
+        members = _members(n_members, model)
         mech = plan.Mechanism(members[0])
         de = ENS.DistributedEnsemble(mech, members, N,
                                      compile_fn=lambda mdef: compile_mechanism(mech, N, defines=mdef))
@@ -80,19 +80,22 @@ def test_expand_members_sweep_and_overrides():
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_ensemble_matches_single_process(tmp_path):
+@pytest.mark.parametrize("model", ["N2", "M2"])
+def test_two_rank_ensemble_matches_single_process(tmp_path, model):
     n_members, N, world = 5, 48, 2
     out = str(tmp_path / "outlet.npy")
-    mp.start_processes(_worker, args=(world, _free_port(), n_members, N, out), nprocs=world,
+    mp.start_processes(_worker, args=(world, _free_port(), n_members, N, out, model), nprocs=world,
                        join=True, start_method="spawn")
     got = np.load(out)
     # single-process reference of the same ensemble
     from oracle.hostemu import HostEmu
-    members = _members(n_members)
+    members = _members(n_members, model)
     mech = plan.Mechanism(members[0])
-    pairs = [plan.member_constants(mi, mech, N) for mi in members]
+    pack, init = ((plan.member_constants, plan.initial_state) if model == "N2"
+                  else (plan.member_constants_m2, plan.initial_state_m2))
+    pairs = [pack(mi, mech, N) for mi in members]
     rows = np.array([r for _, r in pairs])
-    IV = np.array([plan.initial_state(nm, mech, N) for nm, _ in pairs])
+    IV = np.array([init(nm, mech, N) for nm, _ in pairs])
     emu = HostEmu(mech.source(hipbind.kernel_template()), tag="dist", openmp=False)
     y, _ = emu.rk4(IV, rows, N, 2e-6, 25)
     want = y.reshape(n_members, mech.V, N)[:, :, -1]

@@ -2,7 +2,7 @@
 (PyREMOT/docs/pbHomoReactor.py:2694-3015).  The reference integrates the S+2 unknowns
 [c_i, P*, theta] along the dimensionless length with solve_ivp(LSODA) and samples
 t_eval = linspace(0, 1, zNo+1) (:2931); here one launch integrates every member of an ensemble
-(one reactor per lane) with the Rosenbrock(4,3) scheme of the N2 stiff stepper."""
+(one reactor per lane) with the RODAS4 scheme of the N2 stiff stepper."""
 import ctypes as C
 from timeit import default_timer as timer
 

@@ -173,8 +173,8 @@ class N2Device:
                                                 C.c_void_p(self._stats.data_ptr())))
 
     def ros4(self, y, t0, t1, rtol, atol, h0, max_steps):
-        """In place: stiff Rosenbrock(4,3) integration from t0 to t1 with per-reactor step control
-        (needs a code object generated with block <= 256)."""
+        """In place: stiff integration (RODAS4, order 4(3)) from t0 to t1 with per-reactor step control
+        (needs a code object generated with features=("ros4",) and block <= 512; 256 is fastest)."""
         self._chk_state(y)
         if "ros4" not in self.features:
             raise hipbind.RmtN2Error("create the device with features=('ros4',) to use the stiff stepper")

@@ -640,3 +640,19 @@ def test_benchmark_mesh_1024_vs_scipy_on_oracle_rhs(ivp, tol):
         rel = np.abs(got - ref)/np.maximum(np.abs(ref), 1e-30)
         assert np.max(rel) < tol, (k, np.max(rel))
         assert np.max(rel[:, -1]) < 1e-6, (k, np.max(rel[:, -1]))
+
+
+@pytest.mark.parametrize("N", [2, 3, 63, 65])
+def test_tiny_and_wave_boundary_meshes_vs_oracle(N):
+    """smallest meshes the reference accepts (zNo = 2: inlet-fed node + outlet) and sizes straddling
+    one wave: RHS and 10 RK4 steps against the oracle's vectorised restatement"""
+    mi, mech, nm, dev = make_device("dme_script", N)
+    pr = O.setup_n2(mi, N)
+    f = O.make_rhs_vec(pr)
+    y = dev.to_device(pr["IV"])
+    assert rowwise_err(dev.rhs(y).cpu().numpy()[0], f(0.0, pr["IV"]), mech.V) < 1e-12
+    dev.rk4(y, 1e-6, 10)
+    want = O.rk4(0.0, 1e-5, 10, pr["IV"], f, keep=False)
+    assert rowwise_err(y.cpu().numpy()[0], want, mech.V) < 1e-12
+    assert not dev.status().any()
+    dev.close()

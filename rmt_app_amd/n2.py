@@ -19,21 +19,14 @@ FLAG_PRESSURE = 32
 DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "AM", "hip-ab3")
 
 
-def choose_geometry(N, V, fp32=False, E=None, chainable=True):
+def choose_geometry(N, V, fp32=False, E=None):
     """(block, nodes_per_thread) of the generated kernels for E reactors of N nodes.
-    ``chainable`` False (model M2: no chained-workgroup kernel): keep a reactor in ONE workgroup
-    whenever it fits (N <= 1024), else the memory-resident stepper walks it in 512-node blocks.
     The on-chip stepper holds block*npt nodes per workgroup; longer reactors are chained over
     several workgroups (rmt_n2_rk4_chain).  The table is what measured fastest on MI355X
     (profiles/round1_chain.md, round1_shapes.md):
       * big ensembles: 512 threads x 2 nodes (1024-node chunks, 2 waves/SIMD, y_n/acc in LDS);
       * little total work (E*N <= 32768 nodes, e.g. ONE reactor): 128-node chunks so that a
-        single reactor spreads over up to 256 CUs (14.8 us/step at N=4096 vs 199 us on one CU)."""
-    if not chainable:
-        for block in (64, 128, 256, 512):
-            if N <= block:
-                return block, 1
-        return (512, 2) if (N <= 1024 and V <= 8) else (512, 1)
+        single reactor spreads over up to 256 CUs (10.9 us/step at N=4096 vs 199 us on one CU)."""
     if N > 256 and E is not None and E*N <= 256*128:
         return 128, 1
     for block in (64, 128, 256, 512):
@@ -64,7 +57,7 @@ class N2Device:
         assert members.shape[1] == plan.MEMBER_FIXED + mech.S
         self.E = members.shape[0]
         self.members = members
-        b, n = choose_geometry(self.N, mech.V, fp32, self.E, chainable=getattr(mech, 'model', 'N2') != 'M2')
+        b, n = choose_geometry(self.N, mech.V, fp32, self.E)
         self.block, self.npt = int(block or b), int(npt or n)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         tpl = hipbind.kernel_template()

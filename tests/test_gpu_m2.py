@@ -152,3 +152,26 @@ def test_m2_rk4_end_to_end_vs_scipy_on_oracle_rhs():
     ref = M2O.pack_interval(sol.y[:, -1], pr)["dataYs"]
     got = res["dataPack"][-1]["dataYs"]
     assert np.max(np.abs(got - ref)/np.maximum(np.abs(ref), 1e-6)) < 1e-7
+
+
+@pytest.mark.parametrize("N,E,block,npt", [(1000, 1, 128, 1), (4096, 3, 512, 2), (4100, 2, 256, 1)])
+def test_m2_chained_workgroups_match_memory_stepper(N, E, block, npt):
+    """model M2 spread over several workgroups (upstream record awaited before the Newton sweeps):
+    same result as the memory-resident stepper and as the oracle's RK4"""
+    mi, mech, nm, dev = make_device(N, E=E, block=block, npt=npt)
+    IV = np.tile(plan.initial_state_m2(nm, mech, N), (E, 1))
+    dev.set_mode("chain")
+    y = dev.to_device(IV)
+    dev.rk4(y, 2e-6, 40)
+    assert not dev.status().any()
+    dev.set_mode("mem")
+    y2 = dev.to_device(IV)
+    dev.rk4(y2, 2e-6, 40)
+    a, b = y.cpu().numpy(), y2.cpu().numpy()
+    for e in range(E):
+        assert rowwise_err(a[e], b[e], mech.V) < 1e-12
+    if N <= 1000:
+        pr = M2O.setup_m2(mi, N)
+        want = O.rk4(0.0, 40*2e-6, 40, pr["IV"], M2O.make_rhs_vec(pr), keep=False)
+        assert rowwise_err(a[0], want, mech.V) < 1e-11
+    dev.close()

@@ -104,9 +104,9 @@ def test_m2_kernels_cross_compile_for_gfx950():
     mech = plan.Mechanism(INP.m2_dme_input())
     tpl = hipbind.kernel_template()
     code, _ = hipbind.compile_source(mech.source(tpl, False, 128, 1, None, {"RMT_WITH_ROS4": "1"}))
-    for sym in (b"rmt_n2_rhs", b"rmt_n2_rk4_reg", b"rmt_n2_rk4_mem", b"rmt_n2_rk45_mem", b"rmt_n2_ros4_mem"):
+    for sym in (b"rmt_n2_rhs", b"rmt_n2_rk4_reg", b"rmt_n2_rk4_chain", b"rmt_n2_rk4_mem", b"rmt_n2_rk45_mem",
+                b"rmt_n2_ros4_mem"):
         assert sym in code
-    assert b"rmt_n2_rk4_chain" not in code            # M2 has no chained-workgroup stepper
 
 
 def test_m2_result_lists_match_reference_schema():

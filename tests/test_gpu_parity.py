@@ -570,6 +570,18 @@ def test_rmtexe_fp32_dtype_runs_and_is_single_precision_accurate():
     assert 1e-9 < err < 2e-5, err
 
 
+def test_rmtexe_fp32_stiff_stepper_is_single_precision_accurate():
+    """dtype fp32 with the stiff stepper: runs to the end and lands within single-precision
+    distance of the tight reference run (it cannot carry the 1e-6 requirement)"""
+    g = np.load(os.path.join(G, "g4_tight_dme_script_lsoda.npz"))
+    mi = INP.dme_script_input(ivp="hip-ros4")
+    mi["solver-config"].update({"quiet": True, "dtype": "fp32", "rtol": 1e-4, "atol": 1e-7})
+    dp = rmtExe(mi)["resModel"]["dataPack"]
+    for k in range(5):
+        a, b = dp[k]["dataYs"][:, -1], g["dataYs_%d" % k][:, -1]
+        assert np.max(np.abs(a - b)/np.abs(b)) < 5e-5, k
+
+
 def test_full_size_16384_nodes_chain_vs_memory_stepper_and_properties():
     """BASELINE configs[2] size (16384 nodes): the chained on-chip stepper and the memory-resident
     one are independent code paths for the cross-block carries - they must agree; plus

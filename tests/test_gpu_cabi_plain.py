@@ -70,3 +70,46 @@ def test_plain_ctypes_roundtrip():
     L.rmt_n2_destroy(h)
     L.rmt_n2_free(code)
     hip.hipFree(d_y), hip.hipFree(d_f)
+
+
+def test_plain_ctypes_stiff_stepper_and_stats():
+    """rmt_n2_ros4 + rmt_n2_stats through raw device pointers: the reference test case to t = 0.1 s
+    against the tight reference run (golden G4), no torch involved"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    L = hipbind.lib()
+    mi = INP.dme_script_input()
+    N = 20
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, N)
+    src = mech.source(hipbind.kernel_template(), False, 64, 1, None, {"RMT_WITH_ROS4": "1"})
+    code, size, log = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    assert L.rmt_n2_compile(src.encode(), b"gfx950", b"", C.byref(code), C.byref(size), C.byref(log)) == 0
+    p = hipbind.Plan()
+    p.abi_version, p.n_species, p.n_reactions, p.n_vars = 1, mech.S, mech.R, mech.V
+    p.n_nodes, p.n_members, p.fp32, p.block, p.nodes_per_thread = N, 1, 0, 64, 1
+    p.code_object, p.code_size = code, size
+    rows = np.ascontiguousarray(row.reshape(1, -1))
+    p.members = rows.ctypes.data_as(C.POINTER(C.c_double))
+    h = C.c_void_p()
+    assert L.rmt_n2_create(C.byref(p), C.byref(h)) == 0, L.rmt_n2_last_error()
+    y0 = np.ascontiguousarray(plan.initial_state(nm, mech, N))
+    d_y, d_st = C.c_void_p(), C.c_void_p()
+    assert hip.hipMalloc(C.byref(d_y), y0.nbytes) == 0 and hip.hipMalloc(C.byref(d_st), C.sizeof(hipbind.Stats)) == 0
+    assert hip.hipMemcpy(d_y, y0.ctypes.data, y0.nbytes, 1) == 0
+    assert L.rmt_n2_ros4(h, d_y, 0.0, 0.1, 1e-6, 1e-9, 1e-5, 10**6, d_st) == 0, L.rmt_n2_last_error()
+    flags = (C.c_uint32*1)()
+    assert L.rmt_n2_status(h, flags) == 0 and flags[0] == 0          # synchronises
+    st = hipbind.Stats()
+    y = np.empty_like(y0)
+    assert hip.hipMemcpy(C.byref(st), d_st, C.sizeof(hipbind.Stats), 2) == 0
+    assert hip.hipMemcpy(y.ctypes.data, d_y, y0.nbytes, 2) == 0
+    assert st.t_end == 0.1 and 20 < st.accepted < 400 and st.rejected < 40
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_tight_dme_script_lsoda.npz"))
+    ref = np.concatenate([g["dataYCons1_0"].reshape(6, N), g["dataYTemp1_0"].reshape(1, N)])
+    assert np.max(np.abs(y.reshape(7, N)[:, -1] - ref[:, -1])/np.abs(ref[:, -1])) < 1e-6
+    L.rmt_n2_destroy(h)
+    L.rmt_n2_free(code)
+    hip.hipFree(d_y), hip.hipFree(d_st)

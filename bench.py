@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_OPS_PER_NODE_STEP = 1479   # v_*_f64 instructions per node per RK4 step in rmt_n2_rk4_reg (DME, block 512 x 2)
+FP64_OPS_PER_NODE_STEP = 1470   # v_*_f64 instructions per node per RK4 step in rmt_n2_rk4_reg (DME, block 512 x 2)
 N_NODES = 1024
 MEMBERS_PER_GPU = 256
 DT = 2e-6

@@ -296,8 +296,10 @@ def member_constants(modelInput, mech, zNo):
     row[F["F1"]] = 1/(BeVoFr*(zf/vf))                                  # const_F1, :4075
     row[F["FT"]] = vf/zf
     row[F["INV_DZ"]] = float(zNo - 1)
-    row[F["INV_MACOTE"]] = 1.0/GaMaCoTe0[0]
-    row[F["INV_HECOTE"]] = 1.0/GaHeCoTe0
+    # pre-combined on the host (fewer per-reactor scalars in the kernel): FM = F1/GaMaCoTe0 and
+    # GAIN_K = F1/(GaHeCoTe0 * RHO_K * INV_CP0), see rmt_node_post
+    row[F["INV_MACOTE"]] = row[F["F1"]]/GaMaCoTe0[0]
+    row[F["INV_HECOTE"]] = row[F["F1"]]/(GaHeCoTe0*row[F["RHO_K"]]*row[F["INV_CP0"]])
     row[F["UA"]] = U*a
     row[F["TM"]] = Tm
     row[F["CIN"]:F["CIN"] + mech.S] = SpCoi0/Cmax                      # :4090

@@ -294,7 +294,7 @@ def main():
                          # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
                          # profiles/round1_bench_rk4_reg.md): the state once each way, for ANY step
                          # count - known only for the default workload, null otherwise
-                         "traffic": 3.27e7 if (E == MEMBERS_PER_GPU and n_nodes == N_NODES and
+                         "traffic": 3.0e7 if (E == MEMBERS_PER_GPU and n_nodes == N_NODES and
                                               args.mode == "auto") else None,
                          "traffic_unit": "bytes per launch (PMC)",
                          "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step,

@@ -35,6 +35,16 @@ def choose_geometry(N, V, fp32=False, E=None):
     return (512, 2) if V <= 8 else (512, 1)
 
 
+def ros4_block(V, N, fp32=False):
+    """Workgroup size for the stiff stepper: at most 256 threads (one V x V block inverse per lane),
+    and the block's five stage vectors G_1..G_5 must fit in LDS next to the 16 KiB exp table and the
+    hand-over buffers (5*V*block*sizeof(real) <= 140 KiB)."""
+    block = min(256, 64*((N + 63)//64))
+    while block > 64 and 5*V*block*(4 if fp32 else 8) > 140*1024:
+        block //= 2
+    return block
+
+
 def _torch():
     import torch
     if not torch.cuda.is_available():
@@ -335,8 +345,8 @@ def run_n2(modelInput, members_inputs=None):
     named_rows = [plan.member_constants(mi, mech, zNo) for mi in inputs]
     rows = np.array([r for _, r in named_rows])
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
-    if ivp == "hip-ros4" and block is None:      # one VxV matrix per lane: at most 256 threads
-        block, npt = min(256, 64*((zNo + 63)//64)), 1
+    if ivp == "hip-ros4" and block is None:
+        block, npt = ros4_block(mech.V, zNo, fp32), 1
     dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt,
                    features=("ros4",) if ivp == "hip-ros4" else ())
     try:

@@ -327,7 +327,7 @@ extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, doub
         return launch(h, h->f_rk45_reg, args);
     }
     if (!h->f_rk45_mem) return fail("code object has no rk45 kernel");
-    if (ensure_work(h, 8)) return 1;
+    if (ensure_work(h, 10)) return 1;      // K_1..K_7 (when they do not fit in LDS), y_new, K_1/K_7 of the FSAL swap
     void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,
                     (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms,
                     (void*)&stats, (void*)&h->d_flags};

@@ -16,7 +16,7 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import plan
-from .n2 import N2Device, ROUND_FUN_ACCURACY, integrate_intervals, resolve_ivp, ros4_block
+from .n2 import N2Device, ROUND_FUN_ACCURACY, integrate_intervals, resolve_ivp, rk45_block, ros4_block
 from .settings import solverSetting
 
 
@@ -58,6 +58,8 @@ def run_m2(modelInput, members_inputs=None):
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
         block, npt = ros4_block(mech.V, zNo), 1
+    if ivp == "hip-rk45" and block is None:
+        block, npt = rk45_block(mech.V, zNo), 1
     dev = N2Device(mech, rows, zNo, block=block, npt=npt,
                    features=("ros4",) if ivp == "hip-ros4" else ())
     opTSpan = np.linspace(0, opT, tNo + 1)                          # :695

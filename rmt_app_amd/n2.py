@@ -45,6 +45,15 @@ def ros4_block(V, N, fp32=False):
     return block
 
 
+def rk45_block(V, N, fp32=False):
+    """Workgroup size for the adaptive explicit stepper: the largest (<= 256) whose seven stage
+    derivatives of a node block fit in LDS (7*V*block*sizeof(real) <= 112 KiB, csrc RMT_RK45_KLDS)."""
+    block = min(256, 64*((N + 63)//64))
+    while block > 64 and 7*V*block*(4 if fp32 else 8) > 112*1024:
+        block //= 2
+    return block
+
+
 def _torch():
     import torch
     if not torch.cuda.is_available():
@@ -347,6 +356,8 @@ def run_n2(modelInput, members_inputs=None):
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
         block, npt = ros4_block(mech.V, zNo, fp32), 1
+    if ivp == "hip-rk45" and block is None:
+        block, npt = rk45_block(mech.V, zNo, fp32), 1
     dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt,
                    features=("ros4",) if ivp == "hip-ros4" else ())
     try:

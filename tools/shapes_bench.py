@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import inputs as INP  # noqa: E402
 from rmt_app_amd import plan  # noqa: E402
-from rmt_app_amd.n2 import N2Device  # noqa: E402
+from rmt_app_amd.n2 import N2Device, rk45_block  # noqa: E402
 
 
 def run(name, N, E, steps, mode="auto", dt=2e-6, **kw):
@@ -40,7 +40,7 @@ def run_rk45(name, N, E, t1, rtol):
     mi = INP.ALL_N2_INPUTS[name]()
     mech = plan.Mechanism(mi)
     nm, row = plan.member_constants(mi, mech, N)
-    dev = N2Device(mech, np.tile(row, (E, 1)), N)
+    dev = N2Device(mech, np.tile(row, (E, 1)), N, block=rk45_block(mech.V, N), npt=1)     # what rmtExe(ivp="hip-rk45") picks
     y = dev.to_device(np.tile(plan.initial_state(nm, mech, N), (E, 1)))
     dev.rk45(y, 0.0, t1, rtol, 1e-3*rtol, 1e-6, 10**8)
     ms = dev.last_kernel_ms()

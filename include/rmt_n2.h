@@ -66,6 +66,13 @@ extern "C" {
 #define RMT_N2_FLAG_NONFINITE 8u /* a state/derivative became NaN or Inf              */
 #define RMT_N2_FLAG_STEP 16u     /* rk45: step size underflow / max steps exceeded    */
 #define RMT_N2_FLAG_PRESSURE 32u /* model M2: Newton sweeps of the pressure march did not converge */
+/* Contract of the three Python-exception bits: the explicit steppers test the conditions on which the
+ * reference's lambdas would raise on the FIRST stage of every step (f(y_n)); an exception that exists
+ * only at a trial-stage state surfaces as RMT_N2_FLAG_NONFINITE when it poisons the state, and is
+ * not reported when the rate law maps the intermediate inf/nan back to a finite value.  Code objects
+ * generated with RMT_CHECK_ALL_STAGES=1 (solver-config "strict-flags") test every stage.
+ * Every entry point taking a handle runs on the device that was current at rmt_n2_create and
+ * restores the caller's current device before returning. */
 
 /* member row layout: doubles per reactor = 16 + S (see rmt_app_amd/csrc/n2_kernels.inc M_*) */
 #define RMT_N2_MEMBER_FIXED 16
@@ -114,6 +121,10 @@ int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt);
 int rmt_n2_rk4(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t nsteps);
 /* method: 0 = AdBash3, 1 = PreCorr3 (needs nsteps >= 3, like the reference) */
 int rmt_n2_multistep(rmt_n2_handle* h, void* y_inout, double t0, double dt, int64_t nsteps, int method);
+/* h0 > 0: first step of every reactor.  h0 < 0: "resume" - every reactor starts from the h_last
+ * its previous launch left in stats_out[e] (|h0| where that is not a positive finite number);
+ * h_last is the controller's proposal for the step AFTER t1 (a last step clipped to t1 does not
+ * shrink it), so consecutive output intervals chain without a restart transient. */
 int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 int rmt_n2_ros4(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,

@@ -57,6 +57,30 @@ struct rmt_n2_handle {
     bool timed = false;
 };
 
+// Every entry point runs on the device the handle was created on: workspace allocations, event
+// records and module launches all act on the CURRENT device, which the caller may have changed
+// since rmt_n2_create (multi-GPU hosts).  The guard switches to the handle's device and restores the
+// caller's on scope exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(const rmt_n2_handle* h) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != h->device) {
+            err = hipSetDevice(h->device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define ON_DEVICE(h)                                                                        \
+    DeviceGuard guard_(h);                                                                  \
+    if (guard_.err != hipSuccess)                                                           \
+        return fail("cannot switch to device %d of this handle: %s", (h)->device, hipGetErrorString(guard_.err))
+
 extern "C" const char* rmt_n2_last_error(void) { return g_err.c_str(); }
 extern "C" int rmt_n2_abi_version(void) { return RMT_N2_ABI_VERSION; }
 extern "C" const char* rmt_n2_kernel_template(void) { return k_template; }
@@ -179,6 +203,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
 
 extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (!h) return;
+    DeviceGuard guard_(h);
     if (h->d_members) (void)hipFree(h->d_members);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_work) (void)hipFree(h->d_work);
@@ -207,6 +232,7 @@ extern "C" int rmt_n2_set_mode(rmt_n2_handle* h, int mode) {
 
 extern "C" int rmt_n2_set_members(rmt_n2_handle* h, const double* members) {
     if (!h || !members) return fail("null argument");
+    ON_DEVICE(h);
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
     HIP_OK(hipMemcpyAsync(h->d_members, members, mbytes, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
@@ -239,6 +265,7 @@ static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1)
 extern "C" int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms) {
     if (!h || !ms) return fail("null argument");
     if (!h->timed) return fail("no launch recorded yet");
+    ON_DEVICE(h);
     HIP_OK(hipEventSynchronize(h->ev1));
     HIP_OK(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return 0;
@@ -247,6 +274,7 @@ extern "C" int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms) {
 extern "C" int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt) {
     (void)t; /* the N2 right-hand side is autonomous (pbHomoReactor.py:3706: t unused) */
     if (!h || !y || !dydt) return fail("null argument");
+    ON_DEVICE(h);
     int N = h->N;
     void* args[] = {(void*)&y, (void*)&dydt, (void*)&h->d_members, (void*)&N, (void*)&h->d_flags};
     return launch(h, h->f_rhs, args);
@@ -258,6 +286,7 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
     (void)t0;
     if (!h || !y) return fail("null argument");
     if (!(dt > 0) || nsteps < 0) return fail("rk4 needs dt > 0 and nsteps >= 0");
+    ON_DEVICE(h);
     int N = h->N, E = h->E;
     long long ns = (long long)nsteps;
     const bool reg = h->mode == 1 || (h->mode == 0 && fits_registers(h));
@@ -304,6 +333,7 @@ extern "C" int rmt_n2_multistep(rmt_n2_handle* h, void* y, double t0, double dt,
     if (!(dt > 0) || nsteps < 3) return fail("multistep needs dt > 0 and nsteps >= 3");
     if (method != 0 && method != 1) return fail("method must be 0 (AdBash3) or 1 (PreCorr3)");
     if (!h->f_multistep) return fail("code object has no multistep kernel");
+    ON_DEVICE(h);
     if (ensure_work(h, 8)) return 1;
     int N = h->N, E = h->E;
     long long ns = (long long)nsteps;
@@ -315,7 +345,8 @@ extern "C" int rmt_n2_multistep(rmt_n2_handle* h, void* y, double t0, double dt,
 extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, double rtol, double atol,
                            double h0, int64_t max_steps, rmt_n2_stats* stats) {
     if (!h || !y || !stats) return fail("null argument");
-    if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad rk45 arguments");
+    if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 != 0)) return fail("bad rk45 arguments");
+    ON_DEVICE(h);
     int N = h->N, E = h->E;
     long long ms = (long long)max_steps;
     const bool reg = (h->mode == 1 || (h->mode == 0 && fits_registers(h))) && h->f_rk45_reg;
@@ -337,8 +368,9 @@ extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, doub
 extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, double rtol, double atol,
                            double h0, int64_t max_steps, rmt_n2_stats* stats) {
     if (!h || !y || !stats) return fail("null argument");
-    if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad ros4 arguments");
+    if (!(t1 > t0) || !(rtol > 0) || !(atol >= 0) || !(h0 != 0)) return fail("bad ros4 arguments");
     if (!h->f_ros4) return fail("code object has no ros4 kernel");
+    ON_DEVICE(h);
     if (h->block > 512)
         return fail("the Rosenbrock kernel holds a VxV matrix per lane: generate the code object with "
                     "block <= 512 (got %d)", h->block);
@@ -364,6 +396,7 @@ extern "C" int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* ou
     if (!h || !members1 || !out || !stats) return fail("null argument");
     if (nout < 2 || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad N1 arguments");
     if (!h->f_n1) return fail("code object has no N1 kernel");
+    ON_DEVICE(h);
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
     if (!h->d_members1) HIP_OK(hipMalloc((void**)&h->d_members1, mbytes));
     HIP_OK(hipMemcpyAsync(h->d_members1, members1, mbytes, hipMemcpyHostToDevice, h->stream));
@@ -381,6 +414,7 @@ extern "C" int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* ou
 
 extern "C" int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host) {
     if (!h || !flags_host) return fail("null argument");
+    ON_DEVICE(h);
     HIP_OK(hipMemcpyAsync(flags_host, h->d_flags, (size_t)h->E * sizeof(unsigned), hipMemcpyDeviceToHost,
                           h->stream));
     HIP_OK(hipMemsetAsync(h->d_flags, 0, (size_t)h->E * sizeof(unsigned), h->stream));

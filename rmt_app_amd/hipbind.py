@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librmt_n2.so")
+# RMT_N2_LIBRARY selects another build of the same C ABI (the host-ASan build of `make asan`)
+LIB_PATH = os.environ.get("RMT_N2_LIBRARY") or os.path.join(_HERE, "librmt_n2.so")
 CACHE_DIR = os.path.join(_HERE, "_kcache")
 
 ABI_VERSION = 1

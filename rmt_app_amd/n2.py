@@ -114,6 +114,9 @@ class N2Device:
         with torch.cuda.device(self.device):
             hipbind.check(hipbind.lib().rmt_n2_create(C.byref(p), C.byref(h)))
         self.h = h
+        # node-function evaluations one Jacobian of the stiff stepper costs (forward differences: V columns,
+        # +1 in model M2 for the upwind coupling)
+        self.jacobian_evals = mech.V + (1 if getattr(mech, "model", "N2") == "M2" else 0)
         self.dtype = torch.float32 if self.fp32 else torch.float64
         self._stats = torch.zeros((self.E, 4), dtype=torch.float64, device=self.device)
         self.use_current_stream()
@@ -240,6 +243,9 @@ def pack_interval(Y, named, mech, zNo, t_end, modelId):
     S = mech.S
     Y = np.reshape(np.asarray(Y, dtype=np.float64), (mech.V, zNo))
     conc_dl = Y[:-1] if not mech.iso else Y[:]
+    # dataYCons1 is dataYs_Reshaped[:-1] for BOTH process types in the reference (:3636): with V = S
+    # (iso-thermal) that silently drops the last species; the schema is the spec, so it is mirrored
+    cons1 = Y[:-1]
     temp_dl = Y[-1] if not mech.iso else np.repeat(0, zNo).reshape(zNo)
     conc = conc_dl*named["Cmax"]
     T_dl_row = Y[-1, :].reshape((1, zNo)) if not mech.iso else np.repeat(0, zNo).reshape((1, zNo))
@@ -250,7 +256,7 @@ def pack_interval(Y, named, mech, zNo, t_end, modelId):
         "modelId": modelId, "processType": mech.processType, "successStatus": True,
         "dataShape": np.array(t_end).shape, "labelList": labelList, "indexList": [S, S + 1, S],
         "dataTime": t_end, "dataXs": np.linspace(0, 1, zNo),
-        "dataYCons1": conc_dl, "dataYCons2": conc, "dataYTemp1": temp_dl, "dataYTemp2": Treal,
+        "dataYCons1": cons1, "dataYCons2": conc, "dataYTemp1": temp_dl, "dataYTemp2": Treal,
         "dataYs": np.concatenate((mofr, Treal), axis=0),
     }
 
@@ -293,7 +299,6 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
     tNo = len(opTSpan) - 1
     stats = {"steps": 0, "rhs_evals": 0, "node_steps": 0, "accepted": None, "rejected": None}
     _progress(0, tNo + 1, quiet)
-    h_next = None
     for i in range(tNo):
         t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
         _progress(i + 1, tNo + 1, quiet)
@@ -311,27 +316,36 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
             stats["steps"] += n
             stats["rhs_evals"] += (2*n + 6) if ivp == "AM" else (n + 8)
         elif ivp == "hip-ros4":
-            h_next = float(cfg.get('h0', DEVICE_DEFAULTS['ros4-h0'])) if i == 0 else h_next
+            # first interval: h0 for every reactor; later ones RESUME (h0 < 0): each reactor starts from
+            # the step its own controller proposed at the end of the previous interval (stats.h_last)
+            h0 = float(cfg.get('h0', DEVICE_DEFAULTS['ros4-h0']))
             dev.ros4(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['ros4-rtol'])),
-                     float(cfg.get('atol', DEVICE_DEFAULTS['ros4-atol'])), h_next,
+                     float(cfg.get('atol', DEVICE_DEFAULTS['ros4-atol'])), h0 if i == 0 else -h0,
                      int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
         else:
+            h0 = float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0']))
             dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
-                     float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])),
-                     float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0'])),
+                     float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])), h0 if i == 0 else -h0,
                      int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
         dev.raise_on_flags()
         if ivp in ("hip-rk45", "hip-ros4"):
             st = dev.rk45_stats()
-            h_next = float(np.min(st["h_last"]))
             stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
             stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
         on_interval(i, t1, y.cpu().numpy().astype(np.float64))
     if stats["accepted"] is not None:
+        # adaptive steppers: "steps" is already the sum over the members; per attempted step the
+        # Dormand-Prince pair costs 6 RHS evaluations (FSAL; +1 for the first step of a launch), RODAS4
+        # 6 stage evaluations + the node Jacobian (dev.jacobian_evals node-function evaluations)
+        tried = stats["accepted"] + stats["rejected"]
         stats["steps"] = int(np.sum(stats["accepted"]))
-        per = 6 if ivp == "hip-rk45" else 3
-        stats["rhs_evals"] = int(np.sum(per*(stats["accepted"] + stats["rejected"])) + n_members*tNo)
-    stats["node_steps"] = stats["steps"]*zNo*(n_members if ivp != "hip-rk45" else 1)
+        if ivp == "hip-rk45":
+            stats["rhs_evals"] = int(np.sum(6*tried) + n_members*tNo)
+        else:
+            stats["rhs_evals"] = int(np.sum((6 + dev.jacobian_evals)*tried))
+        stats["node_steps"] = stats["steps"]*zNo
+    else:
+        stats["node_steps"] = stats["steps"]*zNo*n_members
     return stats
 
 
@@ -358,7 +372,9 @@ def run_n2(modelInput, members_inputs=None):
         block, npt = ros4_block(mech.V, zNo, fp32), 1
     if ivp == "hip-rk45" and block is None:
         block, npt = rk45_block(mech.V, zNo, fp32), 1
-    dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt,
+    # "strict-flags": test the Python-exception conditions on every RK stage (default: stage 1 only)
+    defines = {"RMT_CHECK_ALL_STAGES": "1"} if cfg.get('strict-flags') else None
+    dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt, defines=defines,
                    features=("ros4",) if ivp == "hip-ros4" else ())
     try:
         IV = np.array([plan.initial_state(nm, mech, zNo) for nm, _ in named_rows])

@@ -557,7 +557,9 @@ def test_rmtexe_isothermal_variant(ivp, extra, tol):
         assert dp[k]["dataYs"].shape == want["dataYs"].shape == (7, 20)
         assert np.max(np.abs(dp[k]["dataYs"] - want["dataYs"])/np.abs(want["dataYs"])) < tol
         np.testing.assert_array_equal(dp[k]["dataYs"][6], 523.0)
-        assert np.shape(dp[k]["dataYCons1"]) == (6, 20) and np.shape(dp[k]["dataYTemp1"]) == (20,)
+        # dataYCons1 = dataYs_Reshaped[:-1] also when V = S (pbHomoReactor.py:3636): 5 rows, like the reference
+        assert np.shape(dp[k]["dataYCons1"]) == (5, 20) and np.shape(dp[k]["dataYTemp1"]) == (20,)
+        assert np.shape(want["dataYCons1"]) == (5, 20)
 
 
 def test_rmtexe_fp32_dtype_runs_and_is_single_precision_accurate():

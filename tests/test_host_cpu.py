@@ -66,6 +66,25 @@ def test_create_rejects_bad_plans_and_reports_errors():
         hipbind.compile_source("this is not HIP")
 
 
+def test_cabi_error_paths_under_asan():
+    """SURVEY section 5 (sanitizer row): the C-ABI host layer built with -fsanitize=address
+    (`make -C rmt_app_amd/csrc asan`; CPU build - GPU ASan is not available on this pool) is driven
+    through its hipRTC compile, error and cleanup paths in a child process that preloads the runtime."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "rmt_app_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rt = subprocess.run(["make", "-s", "-C", csrc, "asan-rt"], capture_output=True, text=True).stdout.strip()
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
+               RMT_N2_LIBRARY=os.path.join(ROOT, "rmt_app_amd", "librmt_n2_asan.so"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "asan_cabi_paths.py")],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "ASAN_CABI_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_product_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

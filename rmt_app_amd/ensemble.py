@@ -10,7 +10,12 @@ communication (``torch.distributed``; backend "nccl" = RCCL over xGMI on the GPU
 CPU tests) is
   * one broadcast from rank 0 of the compiled code object + mechanism digest, so that every rank
     runs the bit-identical kernel without recompiling, and
-  * one gather of the per-member outlet rows / status words to rank 0 per output time.
+  * one gather of the per-member states (``rmtExe``) or outlet rows (``bench.py``) to rank 0 per
+    output time.
+
+``rmtExe`` with ``solver-config.ensemble`` takes this path by itself when the process is a rank of an
+initialised ``torch.distributed`` job (launched under torchrun BEFORE any GPU call): every rank
+integrates its contiguous block, rank 0 returns the full ``resModel["ensemble"]``.
 """
 import copy
 
@@ -91,6 +96,71 @@ def gather_rows(local, counts, dst=0, group=None):
         return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
     dist.gather(padded, None, dst=dst, group=group)
     return None
+
+
+class RankSync:
+    """The process group as seen by rmtExe's ensemble path (run_n2 / run_m2 / run_n1) when
+    torch.distributed is initialised with more than one rank: which members this rank owns, and the
+    three collectives the path needs - agreement on failure, gather of the member states per output
+    time on rank 0, gather of the per-member step counts.  None of them is on the integration path."""
+
+    def __init__(self, n_members, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n_total = int(n_members)
+        self.lo, self.hi = shard(self.n_total, self.world, self.rank)
+        self.counts = [shard(self.n_total, self.world, r)[1] - shard(self.n_total, self.world, r)[0]
+                       for r in range(self.world)]
+        if device is None:      # RCCL moves device tensors, gloo host tensors
+            device = (torch.device("cuda", torch.cuda.current_device())
+                      if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        self.device = device
+
+    def agree(self, err):
+        """Every rank calls this once per output interval with its local exception (or None); if any
+        rank failed, ALL ranks raise - nobody is left waiting in the next gather."""
+        import torch
+        import torch.distributed as dist
+        bad = torch.tensor([0 if err is None else self.rank + 1], dtype=torch.int64, device=self.device)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
+        if err is not None:
+            raise err
+        if int(bad.item()):
+            raise RuntimeError("ensemble integration failed on rank %d (its exception is raised there)"
+                               % (int(bad.item()) - 1))
+
+    def max_int(self, v):
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def gather(self, local):
+        """local: array / tensor [E_local][...] -> numpy [E_total][...] on rank 0, None elsewhere."""
+        import torch
+        t = local if isinstance(local, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(local))
+        shape = tuple(t.shape[1:])
+        t = t.reshape(t.shape[0], -1).to(self.device)
+        out = gather_rows(t, self.counts, 0, self.group)
+        return None if out is None else out.cpu().numpy().reshape((self.n_total,) + shape)
+
+
+def active_ranks(n_members):
+    """RankSync when this process is one rank of an initialised torch.distributed job (world > 1) and the
+    ensemble has at least one member per rank; else None (single-process path)."""
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return None
+    if n_members < dist.get_world_size():
+        raise ValueError("an ensemble of %d members cannot be sharded over %d ranks"
+                         % (n_members, dist.get_world_size()))
+    return RankSync(n_members)
 
 
 class DistributedEnsemble:

@@ -16,7 +16,7 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import plan
-from .n2 import N2Device, ROUND_FUN_ACCURACY, integrate_intervals, resolve_ivp, rk45_block, ros4_block
+from .n2 import ROUND_FUN_ACCURACY, integrate_intervals, open_members, resolve_ivp, rk45_block, ros4_block
 from .settings import solverSetting
 
 
@@ -53,33 +53,39 @@ def run_m2(modelInput, members_inputs=None):
     opT = modelInput['operating-conditions']['period']
     mech = plan.Mechanism(modelInput)
     inputs = list(members_inputs) if members_inputs else [modelInput]
-    named_rows = [plan.member_constants_m2(mi, mech, zNo) for mi in inputs]
-    rows = np.array([r for _, r in named_rows])
+    from .ensemble import active_ranks
+    sync = active_ranks(len(inputs)) if members_inputs else None       # one rank of a torchrun job?
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
         block, npt = ros4_block(mech.V, zNo), 1
     if ivp == "hip-rk45" and block is None:
         block, npt = rk45_block(mech.V, zNo), 1
-    dev = N2Device(mech, rows, zNo, block=block, npt=npt,
-                   features=("ros4",) if ivp == "hip-ros4" else ())
+    dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants_m2, plan.initial_state_m2, sync,
+                                        block=block, npt=npt, features=("ros4",) if ivp == "hip-ros4" else ())
+    packer = sync is None or sync.rank == 0          # rank 0 (or the only process) packs every member
+    n_pack = len(inputs) if packer else 0
     opTSpan = np.linspace(0, opT, tNo + 1)                          # :695
     try:
-        IV = np.array([plan.initial_state_m2(nm, mech, zNo) for nm, _ in named_rows])
         y = dev.to_device(IV)
-        packs = [[] for _ in inputs]
+        packs = [[] for _ in range(n_pack)]
 
         def on_interval(i, t1, Yh):
-            for e in range(len(inputs)):
-                packs[e].append(pack_interval(Yh[e], mech, zNo, t1))
-        stats = integrate_intervals(dev, y, cfg, ivp, opTSpan, len(inputs), zNo, quiet, on_interval)
+            Yg = Yh if sync is None else sync.gather(Yh)
+            if Yg is not None:
+                for e in range(n_pack):
+                    packs[e].append(pack_interval(Yg[e], mech, zNo, t1))
+        stats = integrate_intervals(dev, y, cfg, ivp, opTSpan, len(named_local), zNo, quiet or not packer,
+                                    on_interval, sync)
     finally:
         dev.close()
     ReLe = modelInput['reactor']['ReLe']
-    res = result_lists(packs[0], ReLe, zNo, opTSpan)
-    res["dataPack"] = packs[0]
+    res = result_lists(packs[0] if packs else [], ReLe, zNo, opTSpan)
+    res["dataPack"] = packs[0] if packs else []
     res["computation-time"] = np.round(timer() - start, ROUND_FUN_ACCURACY)
     res["device-stats"] = stats
     if members_inputs:
         res["ensemble"] = [dict(result_lists(p, mi['reactor']['ReLe'], zNo, opTSpan), dataPack=p)
-                           for p, mi in zip(packs, inputs)]
+                           for p, mi in zip(packs, inputs)] if packer else None
+    if sync is not None:
+        res["ensemble-shard"] = {"rank": sync.rank, "world": sync.world, "members": [sync.lo, sync.hi]}
     return res

@@ -51,7 +51,11 @@ def run_n1(modelInput, members_inputs=None):
     zNo = int(cfg.get('zNo', solverSetting['N1']['zNo']))
     nout = zNo + 1
     mech = plan.Mechanism(modelInput)
-    inputs = list(members_inputs) if members_inputs else [modelInput]
+    all_inputs = list(members_inputs) if members_inputs else [modelInput]
+    # as one rank of a torch.distributed job: integrate this rank's contiguous block of profiles
+    from .ensemble import active_ranks
+    sync = active_ranks(len(all_inputs)) if members_inputs else None
+    inputs = all_inputs if sync is None else all_inputs[sync.lo:sync.hi]
     pairs = [plan.member_constants_n1(mi, mech) for mi in inputs]
     rows1 = np.ascontiguousarray(np.array([r for _, r in pairs]))
     # the handle is an N2 handle (same generated module); its N2 member rows are not used here
@@ -65,11 +69,26 @@ def run_n1(modelInput, members_inputs=None):
             dev.h, rows1.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(out.data_ptr()), nout,
             float(cfg.get('rtol', DEVICE_DEFAULTS['n1-rtol'])), float(cfg.get('atol', DEVICE_DEFAULTS['n1-atol'])),
             float(cfg.get('h0', 1e-6)), int(cfg.get('max-steps', 10**7)), C.c_void_p(dev._stats.data_ptr())))
-        dev.raise_on_flags()
+        if sync is None:
+            dev.raise_on_flags()
+        else:
+            err = None
+            try:
+                dev.raise_on_flags()
+            except Exception as e:          # noqa: BLE001 - raised on every rank by agree()
+                err = e
+            sync.agree(err)
         stats = dev.rk45_stats()
         U = out.cpu().numpy()
     finally:
         dev.close()
+    if sync is not None:                    # rank 0 returns every member's profile, the other ranks None
+        U = sync.gather(U)
+        stats = {k: sync.gather(stats[k]) for k in ("accepted", "rejected")}
+        if U is None:
+            return None
+        inputs = all_inputs
+        pairs = [plan.member_constants_n1(mi, mech) for mi in inputs]
     elapsed = np.round(timer() - start, ROUND_FUN_ACCURACY)
     packs = [pack_profile(U[e], pairs[e][0], mech, modelInput['model'], elapsed) for e in range(len(inputs))]
     for p, acc, rej in zip(packs, stats["accepted"], stats["rejected"]):

@@ -293,9 +293,86 @@ def resolve_ivp(ivp):
     return ivp
 
 
-def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_interval):
+FEATURE_DEFINES = {"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}
+
+
+def device_arch():
+    """Architecture the JIT targets: the visible GPU's, gfx950 when there is none (cross-compile)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName.split(":")[0]
+    except Exception:
+        pass
+    return "gfx950"
+
+
+def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=None, npt=None, defines=None,
+                 features=()):
+    """Device + initial state for the members THIS process integrates.
+
+    Single process: all of ``inputs``.  As one rank of a torch.distributed job (``sync``, see
+    ensemble.RankSync): the rank's contiguous block; rank 0 compiles, every rank loads the broadcast
+    code object, sweep-invariant member fields agreed over all ranks become kernel literals.
+    Returns (device, named constants of the local members, local initial states [E_local][V*N])."""
+    if sync is None:
+        pairs = [pack(mi, mech, zNo) for mi in inputs]
+        rows = np.array([r for _, r in pairs])
+        IV = np.array([init(nm, mech, zNo) for nm, _ in pairs])
+        dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt, defines=defines, features=features)
+        return dev, [nm for nm, _ in pairs], IV
+    from .ensemble import DistributedEnsemble
+    E_geo = max(sync.counts)                       # one geometry for all ranks (block sizes differ by <= 1 member)
+    b, n = choose_geometry(zNo, mech.V, fp32, E_geo)
+    block, npt = int(block or b), int(npt or n)
+    defs = dict(defines or {})
+    for f in features:
+        defs[FEATURE_DEFINES[f]] = "1"
+    if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in defs:
+        mine = np.array([pack(mi, mech, zNo)[1] for mi in inputs[sync.lo:sync.hi]])
+        defs["RMT_M2_NEWTON"] = str(sync.max_int(plan.m2_newton_sweeps(mine, mech, zNo)))
+    arch = device_arch()
+    ens = DistributedEnsemble(
+        mech, inputs, zNo, group=sync.group, device=sync.device,
+        compile_fn=lambda mdef: compile_mechanism(mech, zNo, fp32, block, npt, None, {**defs, **mdef}, arch, E_geo))
+    dev = N2Device(mech, ens.rows, zNo, fp32=fp32, block=block, npt=npt, defines={**defs, **ens.member_defines},
+                   specialize=False, code=ens.code, features=features)
+    return dev, ens.named, ens.IV
+
+
+def finish_stats(stats, ivp, n_members, tNo, zNo, jacobian_evals):
+    """Totals of the device-stats record from the per-member step counts."""
+    if stats.get("accepted") is not None:
+        # adaptive steppers: "steps" is the sum over the members; per attempted step the Dormand-Prince
+        # pair costs 6 RHS evaluations (FSAL; +1 for the first step of a launch), RODAS4 6 stage
+        # evaluations + the node Jacobian (jacobian_evals node-function evaluations)
+        tried = stats["accepted"] + stats["rejected"]
+        stats["steps"] = int(np.sum(stats["accepted"]))
+        if ivp == "hip-rk45":
+            stats["rhs_evals"] = int(np.sum(6*tried) + n_members*tNo)
+        else:
+            stats["rhs_evals"] = int(np.sum((6 + jacobian_evals)*tried))
+        stats["node_steps"] = stats["steps"]*zNo
+    else:
+        stats["node_steps"] = stats["steps"]*zNo*n_members
+    return stats
+
+
+def gather_stats(stats, sync, ivp, tNo, zNo, jacobian_evals):
+    """Rank 0: the record for the WHOLE ensemble (per-member step counts gathered); other ranks keep theirs."""
+    if stats.get("accepted") is not None:
+        acc, rej = sync.gather(stats["accepted"]), sync.gather(stats["rejected"])
+        if acc is not None:
+            stats["accepted"], stats["rejected"] = acc, rej
+    n = sync.n_total if sync.rank == 0 else sync.hi - sync.lo
+    stats["ranks"] = sync.world
+    return finish_stats(stats, ivp, n, tNo, zNo, jacobian_evals)
+
+
+def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_interval, sync=None):
     """The reference's time loop (pbHomoReactor.py:3589-3690, pbReactor.py:711-762): one device
-    launch per output interval; ``on_interval(i, t1, Y_host)`` packs the end state."""
+    launch per output interval; ``on_interval(i, t1, Y_host)`` packs the end state.  With ``sync``
+    (multi-rank ensemble) a failure on any rank is raised on every rank before the next gather."""
     tNo = len(opTSpan) - 1
     stats = {"steps": 0, "rhs_evals": 0, "node_steps": 0, "accepted": None, "rejected": None}
     _progress(0, tNo + 1, quiet)
@@ -327,26 +404,23 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
             dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
                      float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])), h0 if i == 0 else -h0,
                      int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
-        dev.raise_on_flags()
+        if sync is None:
+            dev.raise_on_flags()
+        else:
+            err = None
+            try:
+                dev.raise_on_flags()
+            except Exception as e:          # noqa: BLE001 - re-raised on every rank by agree()
+                err = e
+            sync.agree(err)
         if ivp in ("hip-rk45", "hip-ros4"):
             st = dev.rk45_stats()
             stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
             stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
         on_interval(i, t1, y.cpu().numpy().astype(np.float64))
-    if stats["accepted"] is not None:
-        # adaptive steppers: "steps" is already the sum over the members; per attempted step the
-        # Dormand-Prince pair costs 6 RHS evaluations (FSAL; +1 for the first step of a launch), RODAS4
-        # 6 stage evaluations + the node Jacobian (dev.jacobian_evals node-function evaluations)
-        tried = stats["accepted"] + stats["rejected"]
-        stats["steps"] = int(np.sum(stats["accepted"]))
-        if ivp == "hip-rk45":
-            stats["rhs_evals"] = int(np.sum(6*tried) + n_members*tNo)
-        else:
-            stats["rhs_evals"] = int(np.sum((6 + dev.jacobian_evals)*tried))
-        stats["node_steps"] = stats["steps"]*zNo
-    else:
-        stats["node_steps"] = stats["steps"]*zNo*n_members
-    return stats
+    if sync is not None:
+        return gather_stats(stats, sync, ivp, tNo, zNo, dev.jacobian_evals)
+    return finish_stats(stats, ivp, n_members, tNo, zNo, dev.jacobian_evals)
 
 
 def run_n2(modelInput, members_inputs=None):
@@ -365,8 +439,8 @@ def run_n2(modelInput, members_inputs=None):
 
     mech = plan.Mechanism(modelInput)
     inputs = list(members_inputs) if members_inputs else [modelInput]
-    named_rows = [plan.member_constants(mi, mech, zNo) for mi in inputs]
-    rows = np.array([r for _, r in named_rows])
+    from .ensemble import active_ranks
+    sync = active_ranks(len(inputs)) if members_inputs else None       # one rank of a torchrun job?
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
         block, npt = ros4_block(mech.V, zNo, fp32), 1
@@ -374,25 +448,36 @@ def run_n2(modelInput, members_inputs=None):
         block, npt = rk45_block(mech.V, zNo, fp32), 1
     # "strict-flags": test the Python-exception conditions on every RK stage (default: stage 1 only)
     defines = {"RMT_CHECK_ALL_STAGES": "1"} if cfg.get('strict-flags') else None
-    dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt, defines=defines,
-                   features=("ros4",) if ivp == "hip-ros4" else ())
+    dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants, plan.initial_state, sync,
+                                        fp32=fp32, block=block, npt=npt, defines=defines,
+                                        features=("ros4",) if ivp == "hip-ros4" else ())
+    # the process that returns the results (rank 0, or the only one) packs EVERY member
+    packer = sync is None or sync.rank == 0
+    if sync is None:
+        named = named_local
+    else:
+        named = [plan.member_constants(mi, mech, zNo)[0] for mi in inputs] if packer else []
     try:
-        IV = np.array([plan.initial_state(nm, mech, zNo) for nm, _ in named_rows])
         y = dev.to_device(IV)
-        packs = [[] for _ in inputs]
+        packs = [[] for _ in named]
 
         def on_interval(i, t1, Yh):
-            for e, (nm, _) in enumerate(named_rows):
-                packs[e].append(pack_interval(Yh[e], nm, mech, zNo, t1, modelId))
-        stats = integrate_intervals(dev, y, cfg, ivp, np.linspace(0, opT, tNo + 1), len(inputs),
-                                    zNo, quiet, on_interval)
+            Yg = Yh if sync is None else sync.gather(Yh)               # [E_total][V*N] on rank 0
+            if Yg is not None:
+                for e, nm in enumerate(named):
+                    packs[e].append(pack_interval(Yg[e], nm, mech, zNo, t1, modelId))
+        stats = integrate_intervals(dev, y, cfg, ivp, np.linspace(0, opT, tNo + 1), len(named_local),
+                                    zNo, quiet or not packer, on_interval, sync)
     finally:
         dev.close()
     elapsed = np.round(timer() - start, ROUND_FUN_ACCURACY)
-    resPack = {"computation-time": elapsed, "dataPack": packs[0], "device-stats": stats}
+    resPack = {"computation-time": elapsed, "dataPack": packs[0] if packs else [], "device-stats": stats}
     if members_inputs:
-        resPack["ensemble"] = [{"dataPack": p} for p in packs]
-    if displayResult:
+        # multi-rank: rank 0 holds the whole sweep, the other ranks None (and an empty dataPack)
+        resPack["ensemble"] = [{"dataPack": p} for p in packs] if packer else None
+    if sync is not None:
+        resPack["ensemble-shard"] = {"rank": sync.rank, "world": sync.world, "members": [sync.lo, sync.hi]}
+    if displayResult and packer:
         from .plotting import plot_results_dynamic
         plot_results_dynamic(resPack, tNo)
     return resPack

@@ -102,3 +102,84 @@ def test_two_rank_ensemble_matches_single_process(tmp_path, model):
     assert got.shape == (n_members, mech.V)
     np.testing.assert_array_equal(got, want)
     assert np.ptp(got[:, 6]) > 0            # members really differ (inlet T sweep)
+
+
+# ----------------------------------------------------------------------------- rmtExe over the ranks
+def _exe_input(model):
+    if model == "N2":
+        mi = INP.dme_notebook_input(ivp="hip-rk4", period=2e-4)
+        mi["solver-config"].update({"quiet": True, "dt": 2e-6, "zNo": 48, "tNo": 2})
+    else:
+        mi = INP.m2_dme_input(ivp="hip-rk4", period=2e-4)
+        mi["solver-config"].update({"quiet": True, "dt": 2e-6, "zNo": 48, "tNo": 2, "display-result": "False"})
+    mi["solver-config"]["ensemble"] = {"temperature": list(np.linspace(513.0, 533.0, 5)), "pressure": [5.0e6]}
+    return mi
+
+
+def _run_exe(model, fail_member=None):
+    """rmtExe with the device replaced by the host-emulation stand-in (tests/emu_device.py)."""
+    import emu_device
+    from rmt_app_amd import n2, rmtExe
+    n2.N2Device = emu_device.EmuDevice
+    mi = _exe_input(model)
+    if fail_member is not None:          # one member far outside the stable step: its rank raises
+        spec = mi["solver-config"]["ensemble"]
+        mi["solver-config"]["ensemble"] = [
+            {"operating-conditions": {"temperature": float(T)}} for T in spec["temperature"]]
+        mi["solver-config"]["ensemble"][fail_member]["feed"] = {"volumetric-flowrate": 1e3}
+    return rmtExe(mi)["resModel"], emu_device.CREATED
+
+
+def _exe_worker(rank, world, port, out_path, model, fail_member):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if fail_member is not None:
+            try:
+                _run_exe(model, fail_member)
+                raised = "none"
+            except (FloatingPointError, RuntimeError) as e:
+                raised = type(e).__name__
+            with open("%s.%d" % (out_path, rank), "w") as f:
+                f.write(raised)
+            return
+        res, created = _run_exe(model)
+        assert res["ensemble-shard"] == {"rank": rank, "world": world, "members": [0, 3] if rank == 0 else [3, 5]}
+        E, magic, defs = created[-1]
+        assert E == (3 if rank == 0 else 2) and magic == b"\x7fELF"       # rank 0's code object arrived
+        assert "RMT_MC_P0" in defs and "RMT_MC_TF" not in defs                # literals agreed over the ranks
+        if rank == 0:
+            assert len(res["ensemble"]) == 5 and res["device-stats"]["ranks"] == 2
+            np.savez(out_path, **{"m%d_t%d" % (e, k): m["dataPack"][k]["dataYs"]
+                                  for e, m in enumerate(res["ensemble"]) for k in range(2)})
+        else:
+            assert res["ensemble"] is None and res["dataPack"] == []
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("model", ["N2", "M2"])
+def test_rmtexe_shards_the_ensemble_over_ranks(tmp_path, model):
+    """rmtExe itself under a world-size-2 process group: every member's dataPack on rank 0 equals the
+    single-process run bit for bit (same kernel source, same arithmetic, different partition)."""
+    out = str(tmp_path / "exe.npz")
+    mp.start_processes(_exe_worker, args=(2, _free_port(), out, model, None), nprocs=2, join=True,
+                       start_method="spawn")
+    got = np.load(out)
+    res, _ = _run_exe(model)                      # this process: no process group -> single-process path
+    assert "ensemble-shard" not in res and len(res["ensemble"]) == 5
+    for e, m in enumerate(res["ensemble"]):
+        for k in range(2):
+            np.testing.assert_array_equal(got["m%d_t%d" % (e, k)], m["dataPack"][k]["dataYs"])
+    assert np.ptp([m["dataPack"][1]["dataYs"][6, -1] for m in res["ensemble"]]) > 0
+
+
+@pytest.mark.timeout(900)
+def test_rmtexe_failure_on_one_rank_raises_on_all(tmp_path):
+    """A member that blows up on rank 1 must not leave rank 0 waiting in the gather: both ranks raise."""
+    out = str(tmp_path / "fail")
+    mp.start_processes(_exe_worker, args=(2, _free_port(), out, "N2", 4), nprocs=2, join=True,
+                       start_method="spawn")
+    r0, r1 = open(out + ".0").read(), open(out + ".1").read()
+    assert r1 == "FloatingPointError" and r0 == "RuntimeError", (r0, r1)

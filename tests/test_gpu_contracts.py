@@ -56,41 +56,49 @@ def test_chain_stuck_producer_ends_with_step_flag_on_every_member():
     dev.close()
 
 
-def _overflow_in_trial_stage_input():
-    """CH4 case with a rate law whose exp() overflows as soon as the methane mole fraction falls below
-    the feed value: fine at y_0, OverflowError in Python at every later state; 1/(1+inf) = 0 keeps the
-    rate finite."""
+def _overflow_in_trial_stage_input(N=20, dt=1e-3):
+    """CH4 case with a rate law whose exp() overflows as soon as the methane mole fraction has fallen by
+    what half an RK4 step removes: fine at y_0, OverflowError in Python at every trial stage and later
+    state; 1/(1+inf) = 0 keeps the rate itself finite.  The steepness K is chosen from the oracle's K_1 so
+    that the exponent is ~1000 at stage 2 (a clean inf, not an argument so large that exp returns NaN)."""
     import math
-    mi = INP.ch4_input()
-    y_feed = float(np.asarray(mi["feed"]["concentration"])[0]/np.sum(mi["feed"]["concentration"]))
-    mi["reaction-rates"]["VARS"]["y_feed"] = y_feed
-    mi["reaction-rates"]["RATES"] = {
-        "r1": lambda x: x['k0']*(x['C_CH4']**2)*(1.0 + 1.0/(1.0 + math.exp(1e12*(x['y_feed'] - x['y_CH4']))))}
-    return mi
+
+    def build(K):
+        mi = INP.ch4_input()
+        c = np.asarray(mi["feed"]["concentration"], dtype=float)
+        mi["reaction-rates"]["VARS"]["y_feed"] = float(c[0]/c.sum())
+        mi["reaction-rates"]["RATES"] = {
+            "r1": (lambda K: lambda x: x['k0']*(x['C_CH4']**2)*(1.0 + 1.0/(1.0 + math.exp(K*(x['y_feed'] - x['y_CH4'])))))(K)}
+        return mi
+    pr = O.setup_n2(build(0.0), N)
+    y2 = (pr["IV"] + 0.5*dt*O.make_rhs_vec(pr)(0.0, pr["IV"])).reshape(4, N)
+    iv = pr["IV"].reshape(4, N)
+    drop = float(np.max(iv[0, 0]/iv[:3, 0].sum() - y2[0]/y2[:3].sum(0)))   # fall of y_CH4 over half a step
+    return build(1000.0/drop)
 
 
 def test_exception_flags_first_stage_by_default_every_stage_when_strict():
     """include/rmt_n2.h contract: the Python-exception bits are tested on the first stage of a step;
     RMT_CHECK_ALL_STAGES (solver-config 'strict-flags') tests all of them."""
-    mi = _overflow_in_trial_stage_input()
     N = 20
+    mi = _overflow_in_trial_stage_input(N)
     mech = plan.Mechanism(mi)
     nm, row = plan.member_constants(mi, mech, N)
     IV = plan.initial_state(nm, mech, N)
-    # the reference's path raises OverflowError at the first state with y_CH4 < feed
+    # the reference's path raises OverflowError at the stage-2 state of the first step
     pr = O.setup_n2(mi, N)
-    f = O.make_rhs_vec(pr)
-    k1 = f(0.0, pr["IV"])
+    k1 = O.make_rhs_vec(pr)(0.0, pr["IV"])
+    O.rhs_loop(0.0, pr["IV"], pr)
     with pytest.raises(OverflowError):
         O.rhs_loop(0.0, pr["IV"] + 0.5e-3*k1, pr)
     for mode in ("reg", "mem"):
         dev = N2Device(mech, row, N)
         dev.set_mode(mode)
         y = dev.to_device(IV)
-        dev.rk4(y, 1e-3, 1)              # stage 1 at y_0 is clean, stages 2-4 overflow inside the lambda
-        assert not dev.status().any(), mode
+        dev.rk4(y, 1e-3, 1)              # stage 1 at y_0 is clean; stages 2-4 overflow inside the lambda,
+        assert not dev.status().any(), mode          # 1/(1+inf) = 0 hides it: nothing is reported
         assert np.all(np.isfinite(y.cpu().numpy()))
-        dev.rk4(y, 1e-3, 1)              # next step: its first stage sees the overflow
+        dev.rk4(y, 1e-3, 1)              # the next step's first stage sees the overflow
         assert dev.status()[0] & FLAG_OVERFLOW, mode
         dev.close()
         strict = N2Device(mech, row, N, defines={"RMT_CHECK_ALL_STAGES": "1"})

@@ -26,11 +26,39 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_OPS_PER_NODE_STEP = 1470   # v_*_f64 instructions per node per RK4 step in rmt_n2_rk4_reg (DME, block 512 x 2)
+FP64_PEAK_TOPS = 39.3      # 78.6 TFLOP/s fp64 vector spec = 39.3e12 fp64 lane-instructions/s (an FMA counts 2 flops)
 N_NODES = 1024
 MEMBERS_PER_GPU = 256
 DT = 2e-6
 RK4_PER_STEP = 1000          # one bench "step" = one output interval = ONE launch of 1000 RK4 steps (2 ms of reactor time)
+
+
+def tracked_traffic(digest, E, n_nodes):
+    """HBM bytes per launch of the kernel with this code-object digest, from the tracked PMC record
+    profiles/traffic.json (written by tools/record_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command).  None when the record is of another code object or shape -
+    a kernel change invalidates the number instead of leaving a stale one in the line."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None, None
+    ent = rec.get(digest)
+    if not ent or ent.get("members") != E or ent.get("nodes") != n_nodes:
+        return None, None
+    return float(ent["bytes_per_launch"]), ent.get("source")
+
+
+def reference_cpu_rate(n_nodes):
+    """RK4-equivalent node-steps/s of the reference's own Python RHS (profiles/reference_cpu.json, measured in
+    the build container by tools/time_reference.py: the reference cannot travel to the GPU box)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu.json")))
+        case = rec["cases"].get(str(n_nodes)) or rec["cases"]["1024"]
+        return {"value": case["rk4_equiv_node_steps_per_s"], "unit": "mesh-node-steps/s (RK4-equivalent: N/(4 s_per_rhs))",
+                "cores": 1, "where": "build container, %s" % rec["machine"]["cpu"],
+                "source": "profiles/reference_cpu.json (tools/time_reference.py, %s)" % rec["date"]}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def sweep_member_inputs(first, count, total=2048):
@@ -120,8 +148,8 @@ def single_reactor_4096(mech, inputs):
     """BASELINE's target case: ONE 6-species / 3-reaction dynamic reactor on 4096 axial nodes, fp64 -
     explicit RK4 on the device (the reactor chained over 32 workgroups) and the whole 0.5 s job with
     the stiff stepper, next to the same generated source on ONE host core.  The reference's own
-    per-node Python RHS does ~390 RK4-equivalent node-steps/s (measured in the
-    build container; it cannot be run on the GPU box)."""
+    per-node Python RHS: profiles/reference_cpu.json (tools/time_reference.py, measured in the build
+    container; the reference cannot be run on the GPU box)."""
     import torch
     from oracle.hostemu import HostEmu
     from rmt_app_amd import hipbind, plan
@@ -153,10 +181,11 @@ def single_reactor_4096(mech, inputs):
     t0 = time.perf_counter()
     yc, _ = emu.rk4(yc, row, N, DT, 200)
     cpu = N*200/(time.perf_counter() - t0)
+    ref = reference_cpu_rate(1024)
     return {"nodes": N, "rk4_node_steps_per_s": N*2000/(ms*1e-3), "rk4_us_per_step": ms/2.0,
             "ros4_whole_0.5s_job_wall_s": round(wall, 4), "ros4_steps": int(st["accepted"][0] + st["rejected"][0]),
             "flags_ok": bool(ok), "cpu_port_1core_node_steps_per_s": cpu,
-            "reference_python_rk4_equiv_node_steps_per_s": 390.0}
+            "reference_python_rk4_equiv_node_steps_per_s": ref["value"] if ref else None}
 
 
 def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
@@ -268,13 +297,24 @@ def main():
     if rank == 0:
         assert outlet.shape == (total, mech.V) and bool(torch.isfinite(outlet).all())
 
+    code_blob = bytes(dev._code.raw)
     dev.close()
     if rank == 0:
+        from rmt_app_amd import isa
         node_steps = world*E*n_nodes*args.steps*RK4_PER_STEP
         value = node_steps/tmax
         bytes_per_node_step = 2*(mech.S + 2)*8
         # kernel_ms = average launch duration in the timed region (HIP events on the launch stream)
         achieved = (E*n_nodes*RK4_PER_STEP*bytes_per_node_step/1e9)/(kernel_ms/1e3)
+        # fp64 VALU instructions per node-step: counted in the step loop of the code object that was
+        # launched (llvm-objdump), not a constant; HBM traffic: the tracked PMC record of THIS code object
+        kname = "rmt_n2_rk4_%s" % ("mem" if args.mode == "mem" else
+                                   ("reg" if n_nodes <= dev.block*dev.npt else "chain"))
+        ist = isa.kernel_stats(code_blob, kname)
+        loop = ist.get("step_loop") or ist["whole"]
+        f64_ops = loop["valu_f64"]/float(dev.npt)
+        traffic, traffic_src = tracked_traffic(ist["digest"], E, n_nodes)
+        valu_rate = E*n_nodes*RK4_PER_STEP*f64_ops/(kernel_ms/1e3)
         line = {
             "metric": "mesh-node-steps/s (6-sp DME dynamic model); max |\u0394MoFri| vs SciPy ref",
             "value": value, "unit": "mesh-node-steps/s", "n_gpus": world, "steps": args.steps,
@@ -286,29 +326,30 @@ def main():
                        "rk4_steps_per_step": RK4_PER_STEP,
                        "members_per_gpu": E, "nodes": n_nodes, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,
-                       "kernel": "rmt_n2_rk4_%s block=%d npt=%d lds_state=%d" % (
-                           "mem" if args.mode == "mem" else ("reg" if n_nodes <= dev.block*dev.npt else "chain"),
-                           dev.block, dev.npt, dev.lds_state)},
+                       "kernel": "%s block=%d npt=%d lds_state=%d" % (kname, dev.block, dev.npt, dev.lds_state),
+                       "kernel_digest": ist["digest"]},
+            # contract form: ALGORITHMIC bytes (2(S+2)8 B per node-step) / kernel time against the
+            # HBM peak.  The state stays on chip for all steps of a launch, so this is NOT the kernel's HBM
+            # use (that is `measured_hbm_GBs` = PMC traffic / kernel time, ~1000x smaller) and 1/frac is not
+            # bandwidth headroom: the limiter is fp64 VALU issue, priced in `valu_fp64`.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved/HBM_PEAK_GBS,
-                         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-                         # profiles/round1_bench_rk4_reg.md): the state once each way, for ANY step
-                         # count - known only for the default workload, null otherwise
-                         "traffic": 3.0e7 if (E == MEMBERS_PER_GPU and n_nodes == N_NODES and
-                                              args.mode == "auto") else None,
-                         "traffic_unit": "bytes per launch (PMC)",
-                         "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step,
-                         "note": "state stays on chip for all steps of a launch; the limiter is fp64 "
-                                 "VALU issue, see valu_fp64"},
-            # the real ceiling of this kernel: fp64 vector issue (78.6 TFLOP/s spec = 39.3e12 fp64
-            # lane-instructions/s); ops/node-step is the static count in the kernel's ISA
-            "valu_fp64": {"ops_per_node_step": FP64_OPS_PER_NODE_STEP,
-                          "achieved_Tops": E*n_nodes*RK4_PER_STEP*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/1e12,
-                          "peak_Tops": 39.3,
-                          "frac": E*n_nodes*RK4_PER_STEP*FP64_OPS_PER_NODE_STEP/(kernel_ms/1e3)/39.3e12},
+                         "frac": achieved/HBM_PEAK_GBS, "achieved_is": "algorithmic bytes / kernel time",
+                         "limiter": "valu_fp64",
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE+WRITE_SIZE)",
+                         "traffic_source": traffic_src,
+                         "measured_hbm_GBs": (traffic/1e9)/(kernel_ms/1e3) if traffic else None,
+                         "kernel_ms": kernel_ms, "bytes_per_node_step": bytes_per_node_step},
+            # the real ceiling of this kernel: fp64 vector issue; ops/node-step = v_*_f64 instructions in
+            # the step loop of the launched code object / nodes per lane (rmt_app_amd/isa.py)
+            "valu_fp64": {"ops_per_node_step": f64_ops, "ops_source": "llvm-objdump of code object %s, step loop "
+                          "of %s: %d v_*_f64 of %d VALU, %d scratch, %d lane moves" % (
+                              ist["digest"], kname, loop["valu_f64"], loop["valu"], loop["scratch"], loop["lane_moves"]),
+                          "achieved_Tops": valu_rate/1e12, "peak_Tops": FP64_PEAK_TOPS,
+                          "frac": valu_rate/(FP64_PEAK_TOPS*1e12)},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)
+            line["cpu_baseline"]["reference_python"] = reference_cpu_rate(n_nodes)
             line["accuracy"] = accuracy_vs_scipy_reference()
             line["single_reactor_4096"] = single_reactor_4096(mech, inputs)
             line["time_to_solution"] = time_to_solution(mech, rows, IV, n_nodes)

@@ -68,8 +68,9 @@ extern "C" {
 #define RMT_N2_FLAG_PRESSURE 32u /* model M2: Newton sweeps of the pressure march did not converge */
 /* Contract of the three Python-exception bits: the explicit steppers test the conditions on which the
  * reference's lambdas would raise on the FIRST stage of every step (f(y_n)); an exception that exists
- * only at a trial-stage state surfaces as RMT_N2_FLAG_NONFINITE when it poisons the state, and is
- * not reported when the rate law maps the intermediate inf/nan back to a finite value.  Code objects
+ * only at a trial-stage state surfaces as RMT_N2_FLAG_NONFINITE when it poisons the state (the lean
+ * fp64 division and exp of the kernels turn an intermediate inf into NaN - 1/(1+inf) is NaN, not 0 - so
+ * the usual ways of mapping an overflow back to a finite rate do poison it).  Code objects
  * generated with RMT_CHECK_ALL_STAGES=1 (solver-config "strict-flags") test every stage.
  * Every entry point taking a handle runs on the device that was current at rmt_n2_create and
  * restores the caller's current device before returning. */

@@ -70,6 +70,18 @@ class HostEmu:
         self.lib.emu_n1_rhs(u.ctypes.data, out.ctypes.data, members1.ctypes.data, E, flags.ctypes.data)
         return out, flags
 
+    def node_jac(self, y, member, N):
+        """(analytic, forward-difference) node Jacobians -d f_z/d y_z, each [N][V][V], of one reactor state
+        (needs a source generated with defines={"RMT_WITH_ROS4": "1"})."""
+        y = np.ascontiguousarray(y, dtype=self.dtype).reshape(self.V*N)
+        member = np.ascontiguousarray(member, dtype=np.float64).reshape(-1)
+        jan = np.zeros((N, self.V, self.V))
+        jfd = np.zeros((N, self.V, self.V))
+        self.lib.emu_node_jac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.emu_node_jac.restype = None
+        self.lib.emu_node_jac(y.ctypes.data, member.ctypes.data, N, jan.ctypes.data, jfd.ctypes.data)
+        return jan, jfd
+
     def rk4(self, y, members, N, h, nsteps):
         y = np.array(y, dtype=self.dtype).reshape(-1, self.V*N)
         E = y.shape[0]

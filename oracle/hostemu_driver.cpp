@@ -103,3 +103,47 @@ extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_,
         flags[e] |= rmt_flags_bits(f);
     }
 }
+
+#if RMT_WITH_ROS4 && RMT_MODEL == 0
+// Analytic node Jacobian of the stiff stepper (rmt_node_jac) next to the forward-difference one it
+// replaces, for every node of ONE reactor state: jan / jfd are [N][V][V] = -d f_r / d y_c at the
+// frozen (P, upstream state) the RHS evaluation sees.
+extern "C" void emu_node_jac(const real* y, const double* member, int N, double* jan, double* jfd) {
+    RmtMember m;
+    rmt_load_member(member, m);
+    rmt_noflags_t nof;
+    preal P = m.p0;
+    real up[RMT_V];
+    for (int i = 0; i < RMT_S; ++i) up[i] = m.cin[i];
+#if !RMT_ISO
+    up[RMT_S] = m.theta_in;
+#endif
+    for (int z = 0; z < N; ++z) {
+        real ys[RMT_V], k[RMT_V];
+        for (int i = 0; i < RMT_V; ++i) ys[i] = y[(size_t)i * N + z];
+        RmtNode nd;
+        const auto a0 = rmt_node_pre(m, ys, nd);
+        rmt_node_post(m, nd, ys, up, P, k, nof);
+        real a[RMT_V][RMT_V], r[RMT_R];
+        rmt_node_jac(m, nd, ys, P, a, r, nof);
+        for (int rr = 0; rr < RMT_V; ++rr)
+            for (int c = 0; c < RMT_V; ++c) jan[((size_t)z * RMT_V + rr) * RMT_V + c] = (double)a[rr][c];
+        for (int c = 0; c < RMT_V; ++c) {
+            real yp[RMT_V], kp[RMT_V];
+            for (int i = 0; i < RMT_V; ++i) yp[i] = ys[i];
+            const real d = real(RMT_FP32 ? 3e-4 : 1.5e-8) * rmt_max(rmt_abs(ys[c]), real(1e-3));
+            yp[c] += d;
+            RmtNode ndp;
+            (void)rmt_node_pre(m, yp, ndp);
+            rmt_node_post(m, ndp, yp, up, P, kp, nof);
+            for (int rr = 0; rr < RMT_V; ++rr)
+                jfd[((size_t)z * RMT_V + rr) * RMT_V + c] = -(double)(kp[rr] - k[rr]) / (double)(yp[c] - ys[c]);
+        }
+        P = rmt_pressure_next(m, a0, P);
+        for (int i = 0; i < RMT_S; ++i) up[i] = rmt_max(ys[i], RMT_EPS);
+#if !RMT_ISO
+        up[RMT_S] = ys[RMT_S];
+#endif
+    }
+}
+#endif

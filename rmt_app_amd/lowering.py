@@ -382,7 +382,8 @@ class Lowered:
                 fn = {"neg": lambda u: -u, "abs": abs, "exp10": lambda u: 10.0**u,
                       "exp2": lambda u: 2.0**u, "rcp": lambda u: 1.0/u,
                       "expn": lambda u: math.exp(-u), "exp10n": lambda u: 10.0**(-u),
-                      "exp2n": lambda u: 2.0**(-u)}.get(op) or getattr(math, op)
+                      "exp2n": lambda u: 2.0**(-u), "sign": lambda u: (u > 0) - (u < 0),
+                      "step": lambda u: 1.0 if u >= 0 else 0.0}.get(op) or getattr(math, op)
                 env[i] = fn(env[a])
         return [env[o] for o in self.outputs]
 
@@ -550,8 +551,195 @@ class Lowered:
                 new[i] = g2._mk(op, x, y)
         return Lowered(g2, [new[o].i for o in self.outputs], self.S)
 
+    # ---- symbolic gradient (sparse forward mode on the DAG)
+    def gradient(self, wrt=None):
+        """d outputs / d inputs as a DAG: every node carries the dict {input: derivative node} of its
+        NON-ZERO partials (one-hot seeds, so an expression that does not depend on an input never gets
+        a tangent for it), built with constant folding and the identities x*0, x*1, x+0 - the result
+        is close to what one would write by hand.  ``wrt``: input names to differentiate by (default:
+        T and every x_i / C_i the expressions use; P is a frozen parameter of the node Jacobian).
+        Returns a ``Gradient`` (primal outputs + partials) for emission / evaluation."""
+        g = self.g
+        g2 = Graph()
+        new = {}
+        # primal part first: its node ids stay below n_primal, where the exception tests are kept
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            if op == "const":
+                new[i] = g2.const(g.cval(i))
+            elif op == "in":
+                new[i] = g2.inp(a)
+            elif op == "powi":
+                new[i] = g2._mk("powi", new[a].i, b)
+            elif b is None:
+                new[i] = g2._mk(op, new[a].i)
+            else:
+                new[i] = g2._mk(op, new[a].i, new[b].i)
+        n_primal = len(g2.nodes)
+        if wrt is None:
+            wrt = sorted({g.nodes[i][1] for i in self.live if g.nodes[i][0] == "in" and g.nodes[i][1] != "P"})
+        wrt = list(wrt)
+
+        def c(v):
+            return g2.const(v)
+
+        def isc(x, v=None):
+            return g2.is_const(x.i) and (v is None or g2.cval(x.i) == v)
+
+        def add(x, y):
+            if x is None:
+                return y
+            if y is None:
+                return x
+            if isc(x, 0.0):
+                return y
+            if isc(y, 0.0):
+                return x
+            return x._bin("add", x, y, lambda p, q: p + q)
+
+        def sub(x, y):
+            if y is None:
+                return x
+            if x is None:
+                return neg(y)
+            if isc(y, 0.0):
+                return x
+            return x._bin("sub", x, y, lambda p, q: p - q)
+
+        def mul(x, y):
+            if x is None or y is None:
+                return None
+            if isc(x, 0.0) or isc(y, 0.0):
+                return None
+            if isc(x, 1.0):
+                return y
+            if isc(y, 1.0):
+                return x
+            if isc(x, -1.0):
+                return neg(y)
+            if isc(y, -1.0):
+                return neg(x)
+            return x._bin("mul", x, y, lambda p, q: p*q)
+
+        def neg(x):
+            if x is None:
+                return None
+            if g2.nodes[x.i][0] == "neg":
+                return Sym(g2, g2.nodes[x.i][1])
+            return x._un("neg", lambda p: -p)
+
+        def un(op, x):
+            return g2._mk(op, x.i)
+
+        LN10, LN2 = math.log(10.0), math.log(2.0)
+        d = {}
+        for i in sorted(self.live):
+            op, a, b = g.nodes[i]
+            u = new[i]
+            if op == "const":
+                d[i] = {}
+                continue
+            if op == "in":
+                d[i] = {a: c(1.0)} if a in wrt else {}
+                continue
+            A = new[a]
+            da = d[a]
+            if op == "powi":
+                n = b
+                f = mul(c(float(n)), A if n == 2 else (c(1.0) if n == 1 else g2._mk("powi", A.i, n - 1)))
+                d[i] = {k: mul(f, v) for k, v in da.items()}
+                continue
+            if b is not None:
+                B = new[b]
+                db = d[b]
+                keys = list(dict.fromkeys(list(da) + list(db)))
+                out = {}
+                for k in keys:
+                    x, y = da.get(k), db.get(k)
+                    if op == "add":
+                        v = add(x, y)
+                    elif op == "sub":
+                        v = sub(x, y)
+                    elif op == "mul":
+                        v = add(mul(x, B), mul(A, y))
+                    elif op == "div":
+                        v = mul(sub(x, mul(u, y)), un("rcp", B)) if (x is not None or y is not None) else None
+                    elif op == "pow":
+                        t1 = mul(y, un("log", A))
+                        t2 = mul(mul(B, x), un("rcp", A))
+                        v = mul(u, add(t1, t2))
+                    elif op in ("max", "min"):
+                        sel = un("step", sub(A, B) if op == "max" else sub(B, A))
+                        v = add(mul(sel, x), mul(sub(c(1.0), sel), y))
+                    else:
+                        raise LoweringError("no derivative rule for op %r" % op)
+                    if v is not None and not isc(v, 0.0):
+                        out[k] = v
+                d[i] = out
+                continue
+            # unary
+            if op == "neg":
+                f = c(-1.0)
+            elif op == "abs":
+                f = un("sign", A)
+            elif op == "rcp":
+                f = neg(mul(u, u))
+            elif op == "sqrt":
+                f = mul(c(0.5), un("rcp", u))
+            elif op == "exp":
+                f = u
+            elif op == "exp10":
+                f = mul(c(LN10), u)
+            elif op == "exp2":
+                f = mul(c(LN2), u)
+            elif op == "expn":
+                f = neg(u)
+            elif op == "exp10n":
+                f = mul(c(-LN10), u)
+            elif op == "exp2n":
+                f = mul(c(-LN2), u)
+            elif op == "log":
+                f = un("rcp", A)
+            elif op == "log10":
+                f = mul(c(1.0/LN10), un("rcp", A))
+            elif op == "log2":
+                f = mul(c(1.0/LN2), un("rcp", A))
+            elif op == "log1p":
+                f = un("rcp", add(c(1.0), A))
+            elif op == "expm1":
+                f = add(u, c(1.0))
+            elif op == "sin":
+                f = un("cos", A)
+            elif op == "cos":
+                f = neg(un("sin", A))
+            elif op == "tan":
+                f = add(c(1.0), mul(u, u))
+            elif op == "tanh":
+                f = sub(c(1.0), mul(u, u))
+            elif op == "sinh":
+                f = un("cosh", A)
+            elif op == "cosh":
+                f = un("sinh", A)
+            elif op == "atan":
+                f = un("rcp", add(c(1.0), mul(A, A)))
+            elif op in ("sign", "step"):
+                f = None
+            else:
+                raise LoweringError("no derivative rule for op %r" % op)
+            out = {}
+            for k, v in da.items():
+                w = mul(f, v)
+                if w is not None and not isc(w, 0.0):
+                    out[k] = w
+            d[i] = out
+        partial = [{k: v.i for k, v in d[o].items()} for o in self.outputs]
+        return Gradient(g2, [new[o].i for o in self.outputs], partial, self.S, n_primal, wrt)
+
     # ---- HIP C++ emission
-    def emit(self, fname="rmt_kinetics"):
+    def _emit_body(self, nocheck_from=None):
+        """Straight-line code for every live node -> (lines, {node: C expression}).  Nodes with an id
+        >= nocheck_from (the derivative part of a gradient DAG) are printed without the
+        Python-exception tests: they are not expressions the reference evaluates."""
         g = self.g
         lines = []
         name = {}
@@ -643,16 +831,24 @@ class Lowered:
                 e = "rmt_%s(%s)" % (op, A)
             elif op in ("min", "max"):
                 e = "rmt_%s(%s, %s)" % (op, A, B)
+            elif op == "sign":
+                e = "(%s > real(0) ? real(1) : (%s < real(0) ? real(-1) : real(0)))" % (A, A)
+            elif op == "step":
+                e = "(%s >= real(0) ? real(1) : real(0))" % A
             else:
                 raise LoweringError("no device emission for op %r" % op)
             for p in pre:
                 if p.startswith("RMT_CHECK"):
-                    if p in seen_checks:
+                    if p in seen_checks or (nocheck_from is not None and i >= nocheck_from):
                         continue
                     seen_checks.add(p)
                 lines.append("    " + p)
             lines.append("    const real %s = %s;" % (v, e))
             name[i] = v
+        return lines, name
+
+    def emit(self, fname="rmt_kinetics"):
+        lines, name = self._emit_body()
         body = "\n".join(lines)
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
         return (
@@ -661,6 +857,48 @@ class Lowered:
             "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r, FL& flag) {\n"
             "    (void)invT;\n%s\n%s\n}\n"
             % (fname, body, outs))
+
+
+class Gradient(Lowered):
+    """Rates and their non-zero partial derivatives with respect to the node inputs (T, x_i, C_i)."""
+
+    def __init__(self, graph, outputs, partial, nspecies, n_primal, wrt):
+        self.partial, self.n_primal, self.wrt = partial, n_primal, wrt
+        self.n_rates = len(outputs)
+        flat = list(outputs)
+        for p in partial:
+            flat.extend(p.values())
+        Lowered.__init__(self, graph, flat, nspecies)
+        self.rate_outputs = list(outputs)
+
+    def evaluate_all(self, T, P, x, C):
+        """(rates, [{input: d rate / d input}]) on the host - for the tests of the gradient itself."""
+        vals = self.evaluate(T, P, x, C)
+        R = self.n_rates
+        out, pos = [], R
+        for p in self.partial:
+            out.append({k: vals[pos + n] for n, k in enumerate(p)})
+            pos += len(p)
+        return vals[:R], out
+
+    def emit_jac(self, fname="rmt_kinetics_jac"):
+        """Device function: rates r[R] and the partials drdT[R], drdx[R][S], drdC[R][S] (zeros written
+        as literals, which the compiler then removes from the chain rule of the node Jacobian)."""
+        lines, name = self._emit_body(nocheck_from=self.n_primal)
+        S, R = self.S, self.n_rates
+        outs = ["    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.rate_outputs)]
+        for q, p in enumerate(self.partial):
+            outs.append("    drdT[%d] = %s;" % (q, name[p["T"]] if "T" in p else "real(0)"))
+            for i in range(S):
+                outs.append("    drdx[%d][%d] = %s;" % (q, i, name[p["x%d" % i]] if ("x%d" % i) in p else "real(0)"))
+                outs.append("    drdC[%d][%d] = %s;" % (q, i, name[p["C%d" % i]] if ("C%d" % i) in p else "real(0)"))
+        return (
+            "template <typename FL>\n"
+            "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
+            "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r,\n"
+            "        real* __restrict__ drdT, real (*__restrict__ drdx)[RMT_S], real (*__restrict__ drdC)[RMT_S], FL& flag) {\n"
+            "    (void)invT;\n%s\n%s\n}\n"
+            % (fname, "\n".join(lines), "\n".join(outs)))
 
 
 def trace(VARS, RATES, nspecies, R_CONST=8.314472, fixed=None):

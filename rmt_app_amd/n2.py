@@ -54,6 +54,27 @@ def rk45_block(V, N, fp32=False):
     return block
 
 
+def rk45_geometry(V, N, fp32=False):
+    """(block, nodes_per_thread, defines) for the adaptive explicit stepper.  Reactors that fit one
+    workgroup run the on-chip kernel rmt_n2_rk45_reg: 4 long-lived vectors per node, RMT_RK45_LDS of them
+    in LDS (V*block*npt reals each, at most 136 KiB together), the rest in VGPRs - measured on MI355X
+    (profiles/round2_rk45.md): 512 x 2 with 2 vectors in LDS for V <= 8, 256 x 2 for the 12-species
+    mechanism.  Longer reactors use the memory-resident kernel (rk45_block)."""
+    size = 4 if fp32 else 8
+    if V <= 8 and N <= 1024:
+        block, npt = choose_geometry(N, V, fp32)
+    elif N <= 512:
+        block, npt = (256, 2) if N > 256 else (64*((N + 63)//64), 1)
+    else:
+        return rk45_block(V, N, fp32), 1, {}
+    slots = 2
+    while slots > 0 and slots*V*block*npt*size > 136*1024:
+        slots -= 1
+    if slots == 0:
+        return rk45_block(V, N, fp32), 1, {}
+    return block, npt, {"RMT_RK45_LDS": str(slots)}
+
+
 def _torch():
     import torch
     if not torch.cuda.is_available():
@@ -444,10 +465,11 @@ def run_n2(modelInput, members_inputs=None):
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
         block, npt = ros4_block(mech.V, zNo, fp32), 1
-    if ivp == "hip-rk45" and block is None:
-        block, npt = rk45_block(mech.V, zNo, fp32), 1
     # "strict-flags": test the Python-exception conditions on every RK stage (default: stage 1 only)
-    defines = {"RMT_CHECK_ALL_STAGES": "1"} if cfg.get('strict-flags') else None
+    defines = {"RMT_CHECK_ALL_STAGES": "1"} if cfg.get('strict-flags') else {}
+    if ivp == "hip-rk45" and block is None:
+        block, npt, geo_defs = rk45_geometry(mech.V, zNo, fp32)
+        defines.update(geo_defs)
     dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants, plan.initial_state, sync,
                                         fp32=fp32, block=block, npt=npt, defines=defines,
                                         features=("ros4",) if ivp == "hip-ros4" else ())

@@ -198,6 +198,20 @@ class Mechanism:
             lines.append("    if (i == %d) return %s;" % (i, e))
         lines.append("    return real(0);")
         lines.append("}")
+        # d/dT of the above (analytic node Jacobian of the stiff stepper)
+        lines.append("__device__ __forceinline__ real rmt_cp_mean_dT(const int i, const real T) {")
+        for i in range(S):
+            a, b, c, d = (float(v) for v in self.cp_coeff[i])
+            k1, k2, k3 = 0.5*b, 0.5*c, 0.5*d
+            if d != 0.0:
+                e = "(real(%r) * T + real(%r)) * T + real(%r)" % (3.0*k3, 2.0*k2, k1)
+            elif c != 0.0:
+                e = "real(%r) * T + real(%r)" % (2.0*k2, k1)
+            else:
+                e = "real(%r)" % k1
+            lines.append("    if (i == %d) return %s;" % (i, e))
+        lines.append("    return real(0);")
+        lines.append("}")
         return "\n".join(lines) + "\n"
 
     def device_dag(self):
@@ -227,7 +241,11 @@ class Mechanism:
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
         if "RMT_KINETICS_SOURCE" not in template:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
-        body = template.replace("RMT_KINETICS_SOURCE", self.device_dag().emit("rmt_kinetics"), 1)
+        kin = self.device_dag().emit("rmt_kinetics")
+        if (defines or {}).get("RMT_WITH_ROS4") and self.model != "M2":
+            # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i
+            kin += self.device_dag().gradient().emit_jac("rmt_kinetics_jac")
+        body = template.replace("RMT_KINETICS_SOURCE", kin, 1)
         return self.prelude(fp32, block, npt, lds_state, defines) + body
 
     def digest(self, template, fp32, block, npt, lds_state=None, defines=None):

@@ -368,3 +368,61 @@ def test_benchmark_mesh_golden_g8_vs_emulated_rk4(template):
     y, flags = emu.rk4(plan.initial_state(nm, mech, 1024), row, 1024, 2e-6, 50000)
     assert not flags.any()
     assert rowwise_err(y[0], g["states"][0], 7) < 1e-7
+
+
+# ----------------------------------------------------------------------------- analytic node Jacobian
+@pytest.mark.parametrize("name", list(INP.ALL_N2_INPUTS))
+def test_symbolic_gradient_of_the_rate_dag_vs_central_differences(name):
+    """lowering.Lowered.gradient: d rate / d (T, x_i, C_i) of the device DAG against central differences
+    of the same DAG (host evaluation), every non-zero partial; partials the gradient omits are zero."""
+    mech = plan.Mechanism(INP.ALL_N2_INPUTS[name]())
+    dag = mech.device_dag()
+    gr = dag.gradient()
+    assert "P" not in gr.wrt and gr.n_rates == mech.R
+    rng = np.random.default_rng(7)
+    S = mech.S
+    for trial in range(3):
+        x = rng.uniform(0.05, 1.0, S)
+        x /= x.sum()
+        T, P = float(rng.uniform(480, 650)), float(rng.uniform(2e6, 6e6))
+        C = x*P/(8.314472*T)
+        r, dr = gr.evaluate_all(T, P, list(x), list(C))
+        np.testing.assert_allclose(r, dag.evaluate(T, P, list(x), list(C)), rtol=1e-14)
+        for q in range(mech.R):
+            for k in ["T"] + ["x%d" % i for i in range(S)] + ["C%d" % i for i in range(S)]:
+                def at(sign, h=1e-6):
+                    T2, x2, C2 = T, list(x), list(C)
+                    if k == "T":
+                        T2 = T*(1 + sign*h)
+                    elif k[0] == "x":
+                        x2[int(k[1:])] *= 1 + sign*h
+                    else:
+                        C2[int(k[1:])] *= 1 + sign*h
+                    return dag.evaluate(T2, P, x2, C2)[q]
+                base = T if k == "T" else (x[int(k[1:])] if k[0] == "x" else C[int(k[1:])])
+                fd = (at(1) - at(-1))/(2e-6*base)
+                an = dr[q].get(k, 0.0)
+                assert abs(fd - an) <= 1e-7*max(abs(fd), abs(an)) + 1e-9*abs(r[q])/base, (q, k, fd, an)
+
+
+@pytest.mark.parametrize("name,zNo", [("dme_nb", 20), ("dme_script", 20), ("ch4", 20), ("syn12", 20), ("dme_nb", 1024)])
+def test_analytic_node_jacobian_vs_forward_differences(name, zNo, template):
+    """rmt_node_jac (the stiff stepper's analytic -d f_z/d y_z, host build of the generated source) against
+    the V forward differences of the node function it replaces, at the reference-generated G2 states: equal
+    to FD accuracy (~1e-6 of the node's largest entry) wherever no concentration sits on the 1e-30 clamp
+    (at the kink the one-sided difference and the derivative legitimately differ)."""
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    mi = INP.ALL_N2_INPUTS[name]()
+    mech = plan.Mechanism(mi)
+    emu = HostEmu(mech.source(template, defines={"RMT_WITH_ROS4": "1"}), tag="jac_" + name, openmp=False)
+    _, row = plan.member_constants(mi, mech, zNo)
+    V = mech.V
+    checked = 0
+    for Y in g["%s_%d_y" % (name, zNo)]:
+        jan, jfd = emu.node_jac(Y, row, zNo)
+        ok = np.all(Y.reshape(V, zNo)[:mech.S] > 1e-30, axis=0)
+        ok[1:] &= ok[:-1]                       # the upstream node's clamp enters through `up`
+        scale = np.max(np.abs(jfd), axis=(1, 2), keepdims=True)
+        assert np.max((np.abs(jan - jfd)/scale)[ok]) < 2e-5
+        checked += int(ok.sum())
+    assert checked >= zNo

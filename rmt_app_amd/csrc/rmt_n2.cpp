@@ -40,7 +40,10 @@ struct rmt_n2_handle {
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
-                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr, f_n1 = nullptr;
+                  f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr, f_n1 = nullptr,
+                  f_ros4_chain = nullptr;
+    unsigned long long* d_rings = nullptr;   // tagged-word links of the chained stiff stepper: rings, decision slots, abort words
+    size_t ring_bytes = 0;
     double* d_members1 = nullptr;
     unsigned* d_mask = nullptr;
     size_t mask_elems = 0;
@@ -187,6 +190,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     if (hipModuleGetFunction(&h->f_ros4, h->module, "rmt_n2_ros4_mem") != hipSuccess)
         h->f_ros4 = nullptr;
     if (hipModuleGetFunction(&h->f_n1, h->module, "rmt_n1_ros4") != hipSuccess) h->f_n1 = nullptr;
+    if (hipModuleGetFunction(&h->f_ros4_chain, h->module, "rmt_n2_ros4_chain") != hipSuccess) h->f_ros4_chain = nullptr;
     (void)hipGetLastError();
     CREATE_OK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
@@ -211,6 +215,7 @@ extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (h->d_members1) (void)hipFree(h->d_members1);
     if (h->d_sync) (void)hipFree(h->d_sync);
     if (h->d_slots) (void)hipFree(h->d_slots);
+    if (h->d_rings) (void)hipFree(h->d_rings);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->module) (void)hipModuleUnload(h->module);
@@ -374,6 +379,45 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
     if (h->block > 512)
         return fail("the Rosenbrock kernel holds a VxV matrix per lane: generate the code object with "
                     "block <= 512 (got %d)", h->block);
+    // One reactor over several CUs (rmt_n2_ros4_chain): C chunks of W nodes per reactor, T teams, every
+    // workgroup resident (T*C <= #CUs).  Auto mode chains when the ensemble alone cannot fill the device.
+    const int nblocks = (h->N + h->block - 1) / h->block;
+    int C = 1;
+    if (h->f_ros4_chain && h->npt == 1 && nblocks >= 2 && h->mode != 2) {
+        const int per_member = h->n_cus / (h->E < h->n_cus ? h->E : h->n_cus);     // CUs one reactor can have
+        C = nblocks < per_member ? nblocks : per_member;
+        if (C > RMT_N2_MAX_CHUNKS) C = RMT_N2_MAX_CHUNKS;
+        if (h->mode == 0 && 2 * h->E > h->n_cus) C = 1;
+    }
+    if (h->mode == 3 && C < 2)
+        return fail("chained stiff stepper needs >= 2 node blocks per reactor and E < #CUs (N=%d block=%d E=%d CUs=%d)",
+                    h->N, h->block, h->E, h->n_cus);
+    if (C >= 2) {
+        const int bpc = (nblocks + C - 1) / C;          // node blocks per chunk
+        C = (nblocks + bpc - 1) / bpc;
+        int W = bpc * h->block;
+        int T = h->n_cus / C;
+        if (T > h->E) T = h->E;
+        if (ensure_work(h, 1)) return 1;                // y_new
+        const size_t words = 2 * (size_t)(h->V + 1);
+        const size_t ring_words = (size_t)T * C * RMT_N2_RING * words;
+        const size_t need = (ring_words + 2 * (size_t)T) * sizeof(unsigned long long) + (size_t)T * sizeof(unsigned);
+        if (h->ring_bytes < need) {
+            if (h->d_rings) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->d_rings)); }
+            h->d_rings = nullptr; h->ring_bytes = 0;
+            HIP_OK(hipMalloc((void**)&h->d_rings, need));
+            h->ring_bytes = need;
+        }
+        HIP_OK(hipMemsetAsync(h->d_rings, 0, need, h->stream));          // tag 0 never matches: sequence numbers start at 1
+        unsigned long long* decision = h->d_rings + ring_words;
+        unsigned* abort_words = (unsigned*)(decision + 2 * (size_t)T);
+        int N = h->N, E = h->E;
+        long long ms = (long long)max_steps;
+        void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
+                        (void*)&W, (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms,
+                        (void*)&stats, (void*)&h->d_flags, (void*)&h->d_rings, (void*)&decision, (void*)&abort_words};
+        return launch(h, h->f_ros4_chain, args, T * C);
+    }
     // 7 vector arrays + the VxV inverse per node (= V more "vector arrays")
     if (ensure_work(h, 8 + (size_t)h->V)) return 1;   // 7 stage arrays + VxV inverses + upwind coupling (model M2)
     const size_t nmask = (size_t)h->E * h->N;

@@ -384,10 +384,21 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
     const int nblocks = (h->N + h->block - 1) / h->block;
     int C = 1;
     if (h->f_ros4_chain && h->npt == 1 && nblocks >= 2 && h->mode != 2) {
+        // Chunks of ONE node block pipeline stage by stage (a chunk lags its upstream neighbour by a message
+        // latency, ~0.3 stage-block times); chunks of b > 1 blocks run all six stages of a block before the
+        // next one (the block's stage vectors live in LDS), so a downstream chunk starts 6(b-1) stage-block
+        // times late.  Estimated step time in stage-block units, minimised over the chunk count:
         const int per_member = h->n_cus / (h->E < h->n_cus ? h->E : h->n_cus);     // CUs one reactor can have
-        C = nblocks < per_member ? nblocks : per_member;
-        if (C > RMT_N2_MAX_CHUNKS) C = RMT_N2_MAX_CHUNKS;
-        if (h->mode == 0 && 2 * h->E > h->n_cus) C = 1;
+        int cmax = nblocks < per_member ? nblocks : per_member;
+        if (cmax > RMT_N2_MAX_CHUNKS) cmax = RMT_N2_MAX_CHUNKS;
+        double best = 6.0 * nblocks;
+        for (int c = 2; c <= cmax; ++c) {
+            const int b = (nblocks + c - 1) / c;
+            const int cc = (nblocks + b - 1) / b;
+            const double cost = 6.0 * b + (cc - 1) * (6.0 * (b - 1) + 0.3);
+            if (cost < best || (h->mode == 3 && C < 2)) { best = cost; C = cc; }
+        }
+        if (h->mode == 0 && 2 * h->E > h->n_cus) C = 1;       // the ensemble fills the device by itself
     }
     if (h->mode == 3 && C < 2)
         return fail("chained stiff stepper needs >= 2 node blocks per reactor and E < #CUs (N=%d block=%d E=%d CUs=%d)",

@@ -165,15 +165,21 @@ def single_reactor_4096(mech, inputs):
     ok = not dev.status().any()
     dev.close()
     devr = N2Device(mech, row, N, block=256, npt=1, features=("ros4",))
-    y = devr.to_device(IV)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     from rmt_app_amd.settings import DEVICE_DEFAULTS as D
-    devr.ros4(y, 0.0, 0.5, D["ros4-rtol"], D["ros4-atol"], D["ros4-h0"], 10**7)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+    walls = {}
+    for mode in ("mem", "auto"):          # one workgroup (one CU) vs chained over 16 CUs (what auto picks for E = 1)
+        devr.set_mode(mode)
+        y = devr.to_device(IV)
+        devr.ros4(y, 0.0, 1e-4, D["ros4-rtol"], D["ros4-atol"], D["ros4-h0"], 10**7)       # warm-up
+        y = devr.to_device(IV)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        devr.ros4(y, 0.0, 0.5, D["ros4-rtol"], D["ros4-atol"], D["ros4-h0"], 10**7)
+        torch.cuda.synchronize()
+        walls[mode] = time.perf_counter() - t0
+        ok = ok and not devr.status().any()
+    wall = walls["auto"]
     st = devr.rk45_stats()
-    ok = ok and not devr.status().any()
     devr.close()
     emu = HostEmu(mech.source(hipbind.kernel_template()), tag="bench")
     emu.set_threads(1)
@@ -183,9 +189,41 @@ def single_reactor_4096(mech, inputs):
     cpu = N*200/(time.perf_counter() - t0)
     ref = reference_cpu_rate(1024)
     return {"nodes": N, "rk4_node_steps_per_s": N*2000/(ms*1e-3), "rk4_us_per_step": ms/2.0,
-            "ros4_whole_0.5s_job_wall_s": round(wall, 4), "ros4_steps": int(st["accepted"][0] + st["rejected"][0]),
+            "ros4_whole_0.5s_job_wall_s": round(wall, 4), "ros4_one_workgroup_wall_s": round(walls["mem"], 4),
+            "ros4_kernel": "rmt_n2_ros4_chain, 16 chunks of 256 nodes", "ros4_steps": int(st["accepted"][0] + st["rejected"][0]),
             "flags_ok": bool(ok), "cpu_port_1core_node_steps_per_s": cpu,
             "reference_python_rk4_equiv_node_steps_per_s": ref["value"] if ref else None}
+
+
+def adaptive_rk45(mech, rows, IV, n_nodes):
+    """BASELINE configs[4]: adaptive Dormand-Prince RK45 with per-reactor step control on the device
+    (rmt_n2_rk45_reg, on chip) - accepted node-steps/s of this rank's sweep over 8 ms of reactor time after
+    a warm-up interval, and the 12-species / 8-reaction mechanism on 64 x 512 nodes."""
+    import inputs as INP
+    from rmt_app_amd import plan
+    from rmt_app_amd.n2 import N2Device, rk45_geometry
+    out = {}
+    for tag, mech_, rows_, IV_, N, t1 in (("dme_%dx%d" % (len(rows), n_nodes), mech, rows, IV, n_nodes, 8e-3),
+                                          ("syn12_64x512", None, None, None, 512, 0.1)):
+        if mech_ is None:
+            mi = INP.syn12_input()
+            mech_ = plan.Mechanism(mi)
+            nm, row = plan.member_constants(mi, mech_, N)
+            rows_, IV_ = np.tile(row, (64, 1)), np.tile(plan.initial_state(nm, mech_, N), (64, 1))
+        block, npt, defs = rk45_geometry(mech_.V, N)
+        dev = N2Device(mech_, rows_, N, block=block, npt=npt, defines=defs)
+        y = dev.to_device(IV_)
+        dev.rk45(y, 0.0, 1e-5, 1e-6, 1e-9, 1e-6, 10**8)
+        dev.rk45(y, 1e-5, t1, 1e-6, 1e-9, -1e-6, 10**8)
+        ms = dev.last_kernel_ms()
+        st = dev.rk45_stats()
+        ok = not dev.status().any()
+        dev.close()
+        out[tag] = {"accepted_node_steps_per_s": N*float(st["accepted"].sum())/(ms*1e-3), "kernel_ms": ms,
+                    "accepted_per_reactor_median": int(np.median(st["accepted"])),
+                    "rejected_max": int(st["rejected"].max()), "rtol": 1e-6, "atol": 1e-9,
+                    "kernel": "rmt_n2_rk45_%s block=%d npt=%d" % ("reg" if defs else "mem", block, npt), "flags_ok": ok}
+    return out
 
 
 def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
@@ -352,6 +390,7 @@ def main():
             line["cpu_baseline"]["reference_python"] = reference_cpu_rate(n_nodes)
             line["accuracy"] = accuracy_vs_scipy_reference()
             line["single_reactor_4096"] = single_reactor_4096(mech, inputs)
+            line["adaptive_rk45"] = adaptive_rk45(mech, rows, IV, n_nodes)
             line["time_to_solution"] = time_to_solution(mech, rows, IV, n_nodes)
             line["time_to_solution"]["rk4_equivalent_wall_s"] = round(250000*tmax/(args.steps*RK4_PER_STEP), 3)
         print(json.dumps(line))

@@ -34,7 +34,7 @@ RK4_PER_STEP = 1000          # one bench "step" = one output interval = ONE laun
 
 
 def tracked_traffic(digest, E, n_nodes):
-    """HBM bytes per launch of the kernel with this code-object digest, from the tracked PMC record
+    """HBM bytes per launch of the kernel with this machine-code digest (isa.kernel_stats), from the tracked PMC record
     profiles/traffic.json (written by tools/record_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same command).  None when the record is of another code object or shape -
     a kernel change invalidates the number instead of leaving a stale one in the line."""
@@ -351,7 +351,7 @@ def main():
         ist = isa.kernel_stats(code_blob, kname)
         loop = ist.get("step_loop") or ist["whole"]
         f64_ops = loop["valu_f64"]/float(dev.npt)
-        traffic, traffic_src = tracked_traffic(ist["digest"], E, n_nodes)
+        traffic, traffic_src = tracked_traffic(ist["kernel_digest"], E, n_nodes)
         valu_rate = E*n_nodes*RK4_PER_STEP*f64_ops/(kernel_ms/1e3)
         line = {
             "metric": "mesh-node-steps/s (6-sp DME dynamic model); max |\u0394MoFri| vs SciPy ref",
@@ -365,7 +365,7 @@ def main():
                        "members_per_gpu": E, "nodes": n_nodes, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,
                        "kernel": "%s block=%d npt=%d lds_state=%d" % (kname, dev.block, dev.npt, dev.lds_state),
-                       "kernel_digest": ist["digest"]},
+                       "kernel_digest": ist["kernel_digest"], "code_object_digest": ist["digest"]},
             # contract form: ALGORITHMIC bytes (2(S+2)8 B per node-step) / kernel time against the
             # HBM peak.  The state stays on chip for all steps of a launch, so this is NOT the kernel's HBM
             # use (that is `measured_hbm_GBs` = PMC traffic / kernel time, ~1000x smaller) and 1/frac is not

@@ -71,7 +71,10 @@ def kernel_stats(blob, kernel):
         tgt = labels.get(args.split()[-1].strip("<>")) if args else None
         if tgt is not None and tgt < a and (best is None or a - tgt > best[1] - best[0]):
             best = (tgt, a)
-    out = {"kernel": kernel, "digest": code_digest(blob), "whole": _mix(ins)}
+    # identity of THIS kernel's machine code: the mnemonic sequence (operands carry pc-relative literals that move
+    # when another kernel of the same code object changes)
+    kdig = hashlib.sha256("\n".join(op for _, op, _ in ins).encode()).hexdigest()[:24]
+    out = {"kernel": kernel, "digest": code_digest(blob), "kernel_digest": kdig, "whole": _mix(ins)}
     if best:
         loop = [t for t in ins if best[0] <= t[0] <= best[1]]
         out["step_loop"] = _mix(loop)

@@ -745,13 +745,21 @@ class Lowered:
         name = {}
         seen_checks = set()
 
+        table = getattr(self, "_const_table", None)
+
         def lit(v):
             if math.isnan(v):
                 return "real(__builtin_nan(\"\"))"
             if math.isinf(v):
                 return "real(__builtin_inf())" if v > 0 else "real(-__builtin_inf())"
-            r = repr(float(v))
-            return "real(%s)" % r
+            v = float(v)
+            # experiment (emit(const_table=...)): constants that are not hardware inline constants come from a
+            # __constant__ table (scalar loads) instead of s_mov literal pairs
+            if table is not None and v not in (0.0, 0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0):
+                if v not in table:
+                    table[v] = len(table)
+                return "real(RMT_KTAB[%d])" % table[v]
+            return "real(%s)" % repr(v)
 
         for i in sorted(self.live):
             op, a, b = g.nodes[i]
@@ -847,11 +855,20 @@ class Lowered:
             name[i] = v
         return lines, name
 
-    def emit(self, fname="rmt_kinetics"):
+    def emit(self, fname="rmt_kinetics", const_table=False):
+        self._const_table = {} if const_table else None
         lines, name = self._emit_body()
+        table, self._const_table = self._const_table, None
         body = "\n".join(lines)
+        if table:
+            vals = sorted(table, key=table.get)
+            body = "    // literals through the scalar cache\n" + body
+            self._table_decl = ("__constant__ double RMT_KTAB[%d] = {%s};\n"
+                                % (len(vals), ", ".join(repr(v) for v in vals)))
+        else:
+            self._table_decl = ""
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
-        return (
+        return self._table_decl + (
             "template <typename FL>\n"
             "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
             "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r, FL& flag) {\n"

@@ -426,3 +426,60 @@ def test_analytic_node_jacobian_vs_forward_differences(name, zNo, template):
         assert np.max((np.abs(jan - jfd)/scale)[ok]) < 2e-5
         checked += int(ok.sum())
     assert checked >= zNo
+
+
+# ----------------------------------------------------------------------------- round-2 host logic
+def test_rk45_geometry_and_lds_budget():
+    """on-chip RK45 geometry: reactors that fit one workgroup get the on-chip kernel with as many of its four
+    long-lived vectors in LDS as fit 136 KiB; longer ones fall back to the memory-resident kernel's block."""
+    from rmt_app_amd.n2 import rk45_block, rk45_geometry
+    assert rk45_geometry(7, 1024) == (512, 2, {"RMT_RK45_LDS": "2"})
+    assert rk45_geometry(7, 20) == (64, 1, {"RMT_RK45_LDS": "2"})
+    assert rk45_geometry(13, 512) == (256, 2, {"RMT_RK45_LDS": "2"})
+    assert rk45_geometry(7, 4096) == (rk45_block(7, 4096), 1, {})
+    assert rk45_geometry(13, 1024) == (rk45_block(13, 1024), 1, {})
+    for V, N in ((7, 1024), (13, 512), (4, 700), (8, 1024)):
+        block, npt, defs = rk45_geometry(V, N)
+        assert block*npt >= N and int(defs["RMT_RK45_LDS"])*V*block*npt*8 <= 136*1024
+
+
+def test_device_stats_totals():
+    """device-stats: adaptive steppers report the SUM of accepted steps over the members as `steps` and
+    steps*zNo node-steps (round 1 multiplied by the member count once more); RODAS4 = 6 stage evaluations +
+    the node Jacobian per attempted step."""
+    from rmt_app_amd.n2 import finish_stats
+    acc, rej = np.array([10, 12, 9]), np.array([1, 0, 2])
+    st = finish_stats({"steps": 0, "accepted": acc.copy(), "rejected": rej.copy()}, "hip-ros4", 3, 5, 20, 7)
+    assert st["steps"] == 31 and st["node_steps"] == 31*20 and st["rhs_evals"] == int(np.sum((6 + 7)*(acc + rej)))
+    st = finish_stats({"steps": 0, "accepted": acc.copy(), "rejected": rej.copy()}, "hip-rk45", 3, 5, 20, 7)
+    assert st["rhs_evals"] == int(np.sum(6*(acc + rej))) + 3*5 and st["node_steps"] == 31*20
+    st = finish_stats({"steps": 1000, "accepted": None}, "hip-rk4", 3, 5, 20, 7)
+    assert st["node_steps"] == 1000*20*3
+
+
+def test_isa_statistics_of_a_cross_compiled_kernel(template):
+    """rmt_app_amd/isa.py (what bench.py derives its fp64 op count from): the step loop of rmt_n2_rk4_reg is
+    found, dominated by fp64 VALU, and the kernel digest depends on the kernel's code only."""
+    from rmt_app_amd import isa
+    mech = plan.Mechanism(INP.dme_notebook_input())
+    blob = hipbind.compile_cached(mech.source(template, False, 64, 1), mech.digest(template, False, 64, 1), "gfx950")
+    st = isa.kernel_stats(blob, "rmt_n2_rk4_reg")
+    loop = st["step_loop"]
+    assert 1000 < loop["valu_f64"] < 2500 and loop["valu_f64"] > 0.6*loop["valu"] and loop["scratch"] == 0
+    assert loop["instructions"] < st["whole"]["instructions"]
+    res = isa.kernel_resources(blob, "rmt_n2_rk4_reg")
+    assert res["vgpr_count"] <= 256 and res["private_segment_fixed_size"] == 0
+    blob2, _ = hipbind.compile_source(mech.source(template, False, 64, 1, None, {"RMT_RK45_LDS": "1"}))
+    st2 = isa.kernel_stats(blob2, "rmt_n2_rk4_reg")
+    assert st2["digest"] != st["digest"] and st2["kernel_digest"] == st["kernel_digest"]   # another kernel changed
+
+
+def test_traffic_record_is_keyed_by_kernel_digest():
+    import bench
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    (dig, ent), = list(rec.items())[:1]
+    assert bench.tracked_traffic(dig, ent["members"], ent["nodes"])[0] == ent["bytes_per_launch"]
+    assert bench.tracked_traffic("0"*24, ent["members"], ent["nodes"]) == (None, None)
+    assert bench.tracked_traffic(dig, ent["members"] + 1, ent["nodes"]) == (None, None)
+    ref = bench.reference_cpu_rate(1024)
+    assert 100 < ref["value"] < 5000 and ref["cores"] == 1

@@ -71,8 +71,8 @@ def kernel_stats(blob, kernel):
         tgt = labels.get(args.split()[-1].strip("<>")) if args else None
         if tgt is not None and tgt < a and (best is None or a - tgt > best[1] - best[0]):
             best = (tgt, a)
-    # identity of THIS kernel's machine code: the mnemonic sequence (operands carry pc-relative literals that move
-    # when another kernel of the same code object changes)
+    # identity of THIS kernel's machine code: the mnemonic sequence (operands carry pc-relative literals that
+    # move with the layout of the code object)
     kdig = hashlib.sha256("\n".join(op for _, op, _ in ins).encode()).hexdigest()[:24]
     out = {"kernel": kernel, "digest": code_digest(blob), "kernel_digest": kdig, "whole": _mix(ins)}
     if best:

@@ -17,6 +17,7 @@ from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 
 FLAG_PRESSURE = 32
 DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "AM", "hip-ab3")
+FEATURE_DEFINES = {"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}
 
 
 def choose_geometry(N, V, fp32=False, E=None):
@@ -75,6 +76,45 @@ def rk45_geometry(V, N, fp32=False):
     return block, npt, {"RMT_RK45_LDS": str(slots)}
 
 
+def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=None, defines=None,
+                  specialize=None, features=(), have_code=False):
+    """What N2Device compiles for (mechanism, member rows, mesh): geometry, the prelude #defines (optional
+    kernel families, model-M2 sweeps, sweep-invariant member fields as literals) and the translation unit.
+    Needs no GPU - `precompile` uses it to fill the in-tree code-object cache ahead of time."""
+    members = np.ascontiguousarray(members, dtype=np.float64)
+    if members.ndim == 1:
+        members = members.reshape(1, -1)
+    E = members.shape[0]
+    b, n = choose_geometry(int(N), mech.V, fp32, E)
+    block, npt = int(block or b), int(npt or n)
+    defs = dict(defines or {})
+    # optional kernel families: "ros4" (stiff stepper), "n1" (steady-state model); their
+    # unrolled VxV linear algebra is most of the JIT time, so they are compiled on demand
+    for f in features:
+        defs[FEATURE_DEFINES[f]] = "1"
+    if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in defs and not have_code:
+        defs["RMT_M2_NEWTON"] = str(plan.m2_newton_sweeps(members, mech, int(N)))
+    # sweep-invariant member fields become literals (frees SGPRs); a single reactor is NOT
+    # specialised by default - every new operating point would cost a 2-3 s JIT
+    if specialize is None:
+        specialize = E >= 2
+    if specialize:
+        defs.update(plan.uniform_member_defines(members, mech.S))
+    tpl = hipbind.kernel_template()
+    # (the user's lds_state, possibly None, is what selects the per-kernel defaults)
+    src = mech.source(tpl, fp32, block, npt, lds_state, defs)
+    key = mech.digest(tpl, fp32, block, npt, lds_state, defs)
+    return block, npt, defs, src, key
+
+
+def precompile(mech, members, N, arch="gfx950", extra_opts="", **kw):
+    """Cross-compile (hipRTC, no GPU needed) the code object N2Device(mech, members, N, **kw) will load and
+    leave it in the in-tree cache; returns its cache key."""
+    _, _, _, src, key = device_source(mech, members, N, **kw)
+    hipbind.compile_cached(src, key, arch, extra_opts)
+    return key
+
+
 def _torch():
     import torch
     if not torch.cuda.is_available():
@@ -97,28 +137,12 @@ class N2Device:
         assert members.shape[1] == plan.MEMBER_FIXED + mech.S
         self.E = members.shape[0]
         self.members = members
-        b, n = choose_geometry(self.N, mech.V, fp32, self.E)
-        self.block, self.npt = int(block or b), int(npt or n)
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        tpl = hipbind.kernel_template()
-        self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
-        self.defines = dict(defines or {})
-        # optional kernel families: "ros4" (stiff stepper), "n1" (steady-state model); their
-        # unrolled VxV linear algebra is most of the JIT time, so they are compiled on demand
         self.features = tuple(features)
-        for f in self.features:
-            self.defines[{"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}[f]] = "1"
-        if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in self.defines and code is None:
-            self.defines["RMT_M2_NEWTON"] = str(plan.m2_newton_sweeps(members, mech, self.N))
-        # sweep-invariant member fields become literals (frees SGPRs); a single reactor is NOT
-        # specialised by default - every new operating point would cost a 2-3 s JIT
-        if specialize is None:
-            specialize = self.E >= 2
-        if specialize:
-            self.defines.update(plan.uniform_member_defines(members, mech.S))
-        # (the user's lds_state, possibly None, is what selects the per-kernel defaults)
-        src = mech.source(tpl, self.fp32, self.block, self.npt, lds_state, self.defines)
-        key = mech.digest(tpl, self.fp32, self.block, self.npt, lds_state, self.defines)
+        self.block, self.npt, self.defines, src, key = device_source(
+            mech, members, self.N, self.fp32, block, npt, lds_state, defines, specialize, self.features,
+            have_code=code is not None)
+        self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         if code is None:      # an ensemble rank may receive rank 0's code object instead
             code = hipbind.compile_cached(src, key, arch, extra_opts)
@@ -312,9 +336,6 @@ def resolve_ivp(ivp):
         raise ValueError("`ivp` must be one of %s, 'default' or a SciPy method name (got %r)"
                          % (DEVICE_IVPS, ivp))
     return ivp
-
-
-FEATURE_DEFINES = {"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}
 
 
 def device_arch():

@@ -120,14 +120,17 @@ def _run_exe(model, fail_member=None):
     """rmtExe with the device replaced by the host-emulation stand-in (tests/emu_device.py)."""
     import emu_device
     from rmt_app_amd import n2, rmtExe
-    n2.N2Device = emu_device.EmuDevice
-    mi = _exe_input(model)
-    if fail_member is not None:          # one member far outside the stable step: its rank raises
-        spec = mi["solver-config"]["ensemble"]
-        mi["solver-config"]["ensemble"] = [
-            {"operating-conditions": {"temperature": float(T)}} for T in spec["temperature"]]
-        mi["solver-config"]["ensemble"][fail_member]["feed"] = {"volumetric-flowrate": 1e3}
-    return rmtExe(mi)["resModel"], emu_device.CREATED
+    real_device, n2.N2Device = n2.N2Device, emu_device.EmuDevice
+    try:
+        mi = _exe_input(model)
+        if fail_member is not None:          # one member far outside the stable step: its rank raises
+            spec = mi["solver-config"]["ensemble"]
+            mi["solver-config"]["ensemble"] = [
+                {"operating-conditions": {"temperature": float(T)}} for T in spec["temperature"]]
+            mi["solver-config"]["ensemble"][fail_member]["feed"] = {"volumetric-flowrate": 1e3}
+        return rmtExe(mi)["resModel"], emu_device.CREATED
+    finally:
+        n2.N2Device = real_device        # the stand-in must not leak into other tests of this process
 
 
 def _exe_worker(rank, world, port, out_path, model, fail_member):

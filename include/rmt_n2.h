@@ -115,6 +115,10 @@ int rmt_n2_compile(const char* source, const char* arch, const char* extra_opts,
 void rmt_n2_free(void* p);
 /* the device template that rmt_n2_compile expects to follow the generated prelude */
 const char* rmt_n2_kernel_template(void);
+/* path of the hipRTC library this process compiles with (a process that loaded PyTorch first uses the one
+ * PyTorch bundles, otherwise /opt/rocm's; both report version 9.0 but generate different code): part of the key
+ * of any code-object cache */
+const char* rmt_n2_hiprtc_path(void);
 
 int rmt_n2_create(const rmt_n2_plan* plan, rmt_n2_handle** out);
 void rmt_n2_destroy(rmt_n2_handle* h);

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -87,6 +89,12 @@ struct DeviceGuard {
 extern "C" const char* rmt_n2_last_error(void) { return g_err.c_str(); }
 extern "C" int rmt_n2_abi_version(void) { return RMT_N2_ABI_VERSION; }
 extern "C" const char* rmt_n2_kernel_template(void) { return k_template; }
+extern "C" const char* rmt_n2_hiprtc_path(void) {
+    // the shared object hiprtcCompileProgram resolves to in THIS process
+    Dl_info info;
+    if (dladdr((void*)&hiprtcCompileProgram, &info) && info.dli_fname) return info.dli_fname;
+    return "";
+}
 extern "C" void rmt_n2_free(void* p) { free(p); }
 
 extern "C" int rmt_n2_compile(const char* source, const char* arch, const char* extra_opts,

@@ -66,6 +66,7 @@ def lib():
     L.rmt_n1_profile.argtypes = [vp, C.POINTER(dbl), vp, C.c_int, dbl, dbl, dbl, i64, vp]
     L.rmt_n2_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rmt_n2_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rmt_n2_hiprtc_path.restype = cp
     if L.rmt_n2_abi_version() != ABI_VERSION:
         raise RmtN2Error("librmt_n2.so ABI %d != binding ABI %d" % (L.rmt_n2_abi_version(), ABI_VERSION))
     _lib = L
@@ -97,10 +98,31 @@ def compile_source(source, arch="gfx950", extra_opts=""):
     return blob, logtxt
 
 
+_RTC_TAG = None
+
+
+def hiprtc_tag():
+    """Short identity of the hipRTC in this process.  The image has two - /opt/rocm's and the one bundled with
+    PyTorch (used by every process that imported torch before this library); both call themselves 9.0 but
+    generate different code - so the tag is derived from the library file that is actually loaded."""
+    global _RTC_TAG
+    if _RTC_TAG is None:
+        import hashlib
+        path = os.path.realpath(lib().rmt_n2_hiprtc_path().decode() or "unknown")
+        try:
+            size = os.path.getsize(path)
+        except OSError:
+            size = 0
+        _RTC_TAG = hashlib.sha256(("%s:%d" % (path, size)).encode()).hexdigest()[:8]
+    return _RTC_TAG
+
+
 def compile_cached(source, key, arch="gfx950", extra_opts=""):
-    """Code objects are cached in-tree (rmt_app_amd/_kcache/<key>.hsaco): the directory travels
-    with the repo snapshot, a cache under $HOME would not."""
+    """Code objects are cached in-tree (rmt_app_amd/_kcache/<key>-rtc<compiler tag>-<arch>.hsaco): the directory
+    travels with the repo snapshot, a cache under $HOME would not.  The compiler's identity is part of the name,
+    so objects of the two hipRTCs of this image never stand in for each other."""
     os.makedirs(CACHE_DIR, exist_ok=True)
+    key = "%s-rtc%s" % (key, hiprtc_tag())
     if extra_opts:
         import hashlib
         key = "%s-%s" % (key, hashlib.sha256(extra_opts.encode()).hexdigest()[:8])

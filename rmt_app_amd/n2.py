@@ -20,16 +20,23 @@ DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "AM", "hip-ab3")
 FEATURE_DEFINES = {"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}
 
 
+N_CUS = 256          # MI355X; the C library clamps the team count to the device's real CU count
+
+
 def choose_geometry(N, V, fp32=False, E=None):
     """(block, nodes_per_thread) of the generated kernels for E reactors of N nodes.
     The on-chip stepper holds block*npt nodes per workgroup; longer reactors are chained over
     several workgroups (rmt_n2_rk4_chain).  The table is what measured fastest on MI355X
-    (profiles/round1_chain.md, round1_shapes.md):
-      * big ensembles: 512 threads x 2 nodes (1024-node chunks, 2 waves/SIMD, y_n/acc in LDS);
-      * little total work (E*N <= 32768 nodes, e.g. ONE reactor): 128-node chunks so that a
-        single reactor spreads over up to 256 CUs (10.9 us/step at N=4096 vs 199 us on one CU)."""
-    if N > 256 and E is not None and E*N <= 256*128:
-        return 128, 1
+    (profiles/round1_chain.md, round2_shapes.md):
+      * big ensembles: 512 threads x 2 nodes (1024-node chunks, 2 waves/SIMD);
+      * ensembles that would leave at least half of the 256 CUs idle with one workgroup per 1024 nodes:
+        the reactors are cut into 128-, 256- or 512-node chunks (the smallest that keeps E x chunks <= 256
+        workgroups, all resident), e.g. ONE 4096-node reactor over 32 CUs (10.7 us/step vs 217 us on one CU),
+        64 x 1024 nodes as 4 chunks each (1.55x the one-CU-per-reactor rate)."""
+    if N > 256 and E is not None and 2*E*(-(-N//1024)) <= N_CUS:
+        for block, npt in ((128, 1), (256, 1), (256, 2)):
+            if E*(-(-N//(block*npt))) <= N_CUS:
+                return block, npt
     for block in (64, 128, 256, 512):
         if N <= block:
             return block, 1

@@ -330,10 +330,11 @@ def test_rmtexe_am_plug_point():
 
 
 @pytest.mark.parametrize("N,E,block,npt", [(300, 3, 64, 1), (300, 70, 64, 1), (1000, 2, 128, 2),
-                                           (4096, 2, None, None), (5000, 1, None, None)])
+                                           (4096, 2, None, None), (5000, 1, None, None), (1024, 64, None, None)])
 def test_chained_workgroups_agree_with_oracle(N, E, block, npt):
     """One reactor spread over several workgroups (producer->consumer chain of boundary records):
-    ragged chunking, more reactors than teams, and the default geometry at N = 4096."""
+    ragged chunking, more reactors than teams, the default geometry at N = 4096, and a mid-size ensemble
+    (64 x 1024 nodes) that the default geometry cuts into 4 chunks per reactor to fill the CUs."""
     mi = INP.dme_notebook_input()
     mech = plan.Mechanism(mi)
     rows, named = [], []

@@ -266,6 +266,24 @@ static int ensure_work(rmt_n2_handle* h, size_t arrays, size_t extra_bytes = 0) 
     return 0;
 }
 
+// tagged-word links of the chained steppers: [links] rings of RMT_N2_RING entries of 2(V+1) words, then 2 decision
+// words and one abort word per team; cleared before every launch (tag 0 never matches)
+static int ensure_rings(rmt_n2_handle* h, int T, int C, unsigned long long** decision, unsigned** abort_words) {
+    const size_t words = 2 * (size_t)(h->V + 1);
+    const size_t ring_words = (size_t)T * C * RMT_N2_RING * words;
+    const size_t need = (ring_words + 2 * (size_t)T) * sizeof(unsigned long long) + (size_t)T * sizeof(unsigned);
+    if (h->ring_bytes < need) {
+        if (h->d_rings) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->d_rings)); }
+        h->d_rings = nullptr; h->ring_bytes = 0;
+        HIP_OK(hipMalloc((void**)&h->d_rings, need));
+        h->ring_bytes = need;
+    }
+    HIP_OK(hipMemsetAsync(h->d_rings, 0, need, h->stream));
+    *decision = h->d_rings + ring_words;
+    *abort_words = (unsigned*)(*decision + 2 * (size_t)T);
+    return 0;
+}
+
 static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1) {
     HIP_OK(hipEventRecord(h->ev0, h->stream));
     HIP_OK(hipModuleLaunchKernel(f, (unsigned)(grid > 0 ? grid : h->E), 1, 1, (unsigned)h->block, 1, 1, 0,
@@ -329,8 +347,12 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
             h->chain_links = links;
         }
         HIP_OK(hipMemsetAsync(h->d_sync, 0, links * 32 * sizeof(unsigned long long), h->stream));
+        unsigned long long* decision = nullptr;
+        unsigned* abort_words = nullptr;
+        if (ensure_rings(h, T, C, &decision, &abort_words)) return 1;
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
-                        (void*)&dt, (void*)&ns, (void*)&h->d_sync, (void*)&h->d_slots, (void*)&h->d_flags};
+                        (void*)&dt, (void*)&ns, (void*)&h->d_sync, (void*)&h->d_slots, (void*)&h->d_flags,
+                        (void*)&h->d_rings, (void*)&abort_words};
         return launch(h, h->f_rk4_chain, args, T * C);
     }
     if (ensure_work(h, 3)) return 1;
@@ -418,18 +440,9 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
         int T = h->n_cus / C;
         if (T > h->E) T = h->E;
         if (ensure_work(h, 1)) return 1;                // y_new
-        const size_t words = 2 * (size_t)(h->V + 1);
-        const size_t ring_words = (size_t)T * C * RMT_N2_RING * words;
-        const size_t need = (ring_words + 2 * (size_t)T) * sizeof(unsigned long long) + (size_t)T * sizeof(unsigned);
-        if (h->ring_bytes < need) {
-            if (h->d_rings) { HIP_OK(hipStreamSynchronize(h->stream)); HIP_OK(hipFree(h->d_rings)); }
-            h->d_rings = nullptr; h->ring_bytes = 0;
-            HIP_OK(hipMalloc((void**)&h->d_rings, need));
-            h->ring_bytes = need;
-        }
-        HIP_OK(hipMemsetAsync(h->d_rings, 0, need, h->stream));          // tag 0 never matches: sequence numbers start at 1
-        unsigned long long* decision = h->d_rings + ring_words;
-        unsigned* abort_words = (unsigned*)(decision + 2 * (size_t)T);
+        unsigned long long* decision = nullptr;
+        unsigned* abort_words = nullptr;
+        if (ensure_rings(h, T, C, &decision, &abort_words)) return 1;
         int N = h->N, E = h->E;
         long long ms = (long long)max_steps;
         void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,

@@ -27,3 +27,32 @@ for model, N, E, steps in (("N2", 16384, 64, 20000), ("N2", 4096, 1, 100000), ("
     print(model, N, E, steps, "%.0f ms" % ms, "flags", int(f1.max()), int(f2.max()), "one launch == 20 launches:", bool(np.array_equal(a, b)),
           "finite:", bool(np.isfinite(a).all()), flush=True)
     dev.close()
+
+# chained STIFF stepper: the whole 0.5 s transient, repeatedly, one reactor and a small ensemble; step history and
+# result must equal the one-workgroup kernel's every time (bitwise identical across repeats of the same kernel)
+from rmt_app_amd.settings import DEVICE_DEFAULTS as D
+for N, E, reps in ((4096, 1, 10), (1024, 40, 10), (16384, 2, 3)):
+    mi = INP.dme_notebook_input()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants(mi, mech, N)
+    IV = np.tile(plan.initial_state(nm, mech, N), (E, 1))
+    dev = N2Device(mech, np.tile(row, (E, 1)), N, block=256, npt=1, features=("ros4",))
+    ref = None
+    ok = True
+    for mode, n in (("mem", 1), ("chain", reps)):
+        dev.set_mode(mode)
+        for r in range(n):
+            y = dev.to_device(IV)
+            dev.ros4(y, 0.0, 0.5, D["ros4-rtol"], D["ros4-atol"], D["ros4-h0"], 10**7)
+            fl = dev.status()
+            st = dev.rk45_stats()
+            out = y.cpu().numpy()
+            if mode == "mem":
+                ref, ref_acc = out, st["accepted"].copy()
+            else:
+                if r == 0:
+                    first = out
+                ok = ok and not fl.any() and np.array_equal(st["accepted"], ref_acc) and np.array_equal(out, first) \
+                    and float(np.max(np.abs(out - ref)/np.maximum(np.abs(ref), 1e-300))) < 1e-6
+    print("ros4 chain soak N=%d E=%d x%d: %s (accepted %d)" % (N, E, reps, "ok" if ok else "MISMATCH", int(ref_acc[0])), flush=True)
+    dev.close()

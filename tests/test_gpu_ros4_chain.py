@@ -110,3 +110,22 @@ def test_chained_stiff_stepper_stuck_producer_ends_with_step_flag():
         dev.ros4(y, 0.0, 5e-3, 1e-6, 1e-9, 1e-5, 10**6)
         dev.raise_on_flags()
     dev.close()
+
+
+def test_chained_stiff_stepper_fp32():
+    """dtype fp32 (state and kinetics in float, pressure scan and the links in double): the chained and the
+    one-workgroup kernel take the same steps and agree to single precision."""
+    N, temps = 1024, (513, 533)
+    mech, rows, IV, _ = _members(N, temps)
+    dev = N2Device(mech, rows, N, fp32=True, block=256, npt=1, features=("ros4",))
+    out, acc = {}, {}
+    for mode in ("mem", "chain"):
+        dev.set_mode(mode)
+        y = dev.to_device(IV)
+        dev.ros4(y, 0.0, 0.01, 1e-4, 1e-7, 1e-5, 10**6)
+        assert not dev.status().any(), mode
+        out[mode], acc[mode] = y.cpu().numpy().astype(np.float64).reshape(2, 7, N), dev.rk45_stats()["accepted"].copy()
+    assert np.all(np.abs(acc["chain"] - acc["mem"]) <= 2), acc
+    scale = np.max(np.abs(out["mem"]), axis=2, keepdims=True)
+    assert np.max(np.abs(out["chain"] - out["mem"])/scale) < 1e-4
+    dev.close()

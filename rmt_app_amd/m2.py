@@ -16,7 +16,8 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import plan
-from .n2 import ROUND_FUN_ACCURACY, integrate_intervals, open_members, resolve_ivp, rk45_geometry, ros4_block
+from .n2 import (ROUND_FUN_ACCURACY, integrate_intervals, open_auto, open_members, resolve_ivp, rk45_geometry,
+                 ros4_block)
 from .settings import solverSetting
 
 
@@ -61,9 +62,13 @@ def run_m2(modelInput, members_inputs=None):
     defines = {}
     if ivp == "hip-rk45" and block is None:
         block, npt, defines = rk45_geometry(mech.V, zNo)
-    dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants_m2, plan.initial_state_m2, sync,
-                                        block=block, npt=npt, defines=defines,
-                                        features=("ros4",) if ivp == "hip-ros4" else ())
+    if ivp == "hip-auto":               # the reference's LSODA: automatic stiff / non-stiff choice (n2.AutoStepper)
+        dev, named_local, IV = open_auto(mech, inputs, zNo, plan.member_constants_m2, plan.initial_state_m2, sync,
+                                         False, None, block, npt)
+    else:
+        dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants_m2, plan.initial_state_m2, sync,
+                                            block=block, npt=npt, defines=defines,
+                                            features=("ros4",) if ivp == "hip-ros4" else ())
     packer = sync is None or sync.rank == 0          # rank 0 (or the only process) packs every member
     n_pack = len(inputs) if packer else 0
     opTSpan = np.linspace(0, opT, tNo + 1)                          # :695

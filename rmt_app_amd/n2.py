@@ -16,7 +16,7 @@ from .lowering import FLAG_DIV0, FLAG_DOMAIN, FLAG_NONFINITE, FLAG_OVERFLOW, FLA
 from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 
 FLAG_PRESSURE = 32
-DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "AM", "hip-ab3")
+DEVICE_IVPS = ("hip-rk4", "hip-rk45", "hip-ros4", "hip-auto", "AM", "hip-ab3")
 FEATURE_DEFINES = {"ros4": "RMT_WITH_ROS4", "n1": "RMT_WITH_N1"}
 
 
@@ -289,6 +289,132 @@ class N2Device:
         raise RuntimeError("device error in " + where)
 
 
+class AutoStepper:
+    """ivp "hip-auto": the device counterpart of LSODA's automatic method switching (what the reference's default
+    `solve_ivp(..., method="LSODA")` does, pbHomoReactor.py:3576, 3609), decided per output interval and for the
+    whole ensemble at once:
+
+      * the first interval starts with a PROBE: at most `auto-probe-steps` Dormand-Prince steps.  If they reach
+        the end of the interval the problem is not stiff at this scale and the explicit pair carries on.
+      * otherwise the step size the controller settled on tells how many explicit steps the interval would cost
+        ((t1 - t0) / min h_last: the explicit pair sits at its stability limit ~3.3/|lambda| on a stiff problem).
+        Up to `auto-max-explicit-steps` the interval is redone with the explicit pair, beyond that the
+        Rosenbrock stepper takes over - for good (chemistry gets stiffer as the bed heats up, not milder).
+      * an explicit interval that exhausts its step budget is redone with the stiff stepper as well, and one that
+        needed more than `auto-max-explicit-steps` steps is the last explicit one.
+
+    Two devices (the on-chip RK45 geometry and the Rosenbrock kernel family) share the state tensor."""
+
+    def __init__(self, dev_rk45, dev_ros4):
+        """dev_ros4: the stiff device, or a zero-argument factory for it (single-process runs build - and JIT-
+        compile - the Rosenbrock kernel family only when the problem turns out to be stiff)."""
+        self.d45, self._dr = dev_rk45, dev_ros4
+        self.mode = None                    # None: undecided, "rk45", "ros4"
+        self.last = dev_rk45
+        self.rhs_evals = 0
+        self.choices = []
+        self.jacobian_evals = dev_rk45.jacobian_evals
+        self.prev_steps = 0
+        self._started = {"rk45": False, "ros4": False}
+
+    @property
+    def dr(self):
+        if callable(self._dr):
+            self._dr = self._dr()
+        return self._dr
+
+    def to_device(self, y):
+        return self.d45.to_device(y)
+
+    def close(self):
+        self.d45.close()
+        if not callable(self._dr):
+            self._dr.close()
+
+    def rk45_stats(self):
+        return self.last.rk45_stats()
+
+    def raise_on_flags(self):
+        self.last.raise_on_flags()
+
+    def _run(self, which, y, t0, t1, cfg, max_steps):
+        dev = self.d45 if which == "rk45" else self.dr
+        first = not self._started[which]
+        self._started[which] = True
+        if which == "rk45":
+            h0 = float(cfg.get('h0', DEVICE_DEFAULTS['rk45-h0']))
+            dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['auto-rk45-rtol'])),
+                     float(cfg.get('atol', DEVICE_DEFAULTS['auto-rk45-atol'])), h0 if first else -h0, int(max_steps))
+        else:
+            h0 = float(cfg.get('h0', DEVICE_DEFAULTS['ros4-h0']))
+            dev.ros4(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['ros4-rtol'])),
+                     float(cfg.get('atol', DEVICE_DEFAULTS['ros4-atol'])), h0 if first else -h0, int(max_steps))
+        self.last = dev
+        return dev
+
+    def _explicit(self, y, t0, t1, cfg, budget):
+        """One explicit attempt; True when every reactor reached t1 (other failures are left for raise_on_flags)."""
+        dev = self._run("rk45", y, t0, t1, cfg, budget)
+        st = dev.rk45_stats()
+        tried = st["accepted"] + st["rejected"]
+        self.rhs_evals += int(np.sum(6*tried) + dev.E)
+        done = bool(np.all(st["t_end"] >= t1))
+        if not done:
+            flags = dev.status()            # read and clear: only the step budget may be set
+            other = flags & ~np.uint32(FLAG_STEP)
+            if other.any():                 # a genuine failure: put it back for the caller to raise
+                raise _flag_error(int(other[np.nonzero(other)[0][0]]), int(np.nonzero(other)[0][0]), dev.E)
+        return done, st
+
+    def advance(self, y, t0, t1, cfg):
+        hard_max = int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps']))
+        if self.mode != "ros4":
+            backup = y.clone()
+            if self.mode is None:
+                done, st = self._explicit(y, t0, t1, cfg, min(hard_max, DEVICE_DEFAULTS['auto-probe-steps']))
+                if done:
+                    self.mode = "rk45"
+                else:
+                    hmin = float(np.min(st["h_last"]))
+                    est = (t1 - t0)/max(hmin, 1e-300)
+                    y.copy_(backup)
+                    self._started["rk45"] = False
+                    self.mode = "rk45" if est <= DEVICE_DEFAULTS['auto-max-explicit-steps'] else "ros4"
+                    if self.mode == "rk45":
+                        done, st = self._explicit(y, t0, t1, cfg, min(hard_max, int(4*est) + 200))
+                        if not done:
+                            y.copy_(backup)
+                            self.mode = "ros4"
+            else:
+                done, st = self._explicit(y, t0, t1, cfg, min(hard_max, 4*self.prev_steps + 200))
+                if not done:
+                    y.copy_(backup)
+                    self.mode = "ros4"
+            if self.mode == "rk45":
+                self.prev_steps = int(np.max(st["accepted"] + st["rejected"]))
+                self.choices.append("rk45")
+                if self.prev_steps > DEVICE_DEFAULTS['auto-max-explicit-steps']:
+                    self.mode = "ros4"          # the interval just taken was too expensive explicitly: hand over
+                return
+        dev = self._run("ros4", y, t0, t1, cfg, hard_max)
+        st = dev.rk45_stats()
+        self.rhs_evals += int(np.sum((6 + dev.jacobian_evals)*(st["accepted"] + st["rejected"])))
+        self.choices.append("ros4")
+
+
+def _flag_error(f, idx, E):
+    where = "reactor %d of %d (flags=0x%x)" % (idx, E, f)
+    if f & FLAG_DOMAIN:
+        return ValueError("math domain error in " + where)
+    if f & FLAG_DIV0:
+        return ZeroDivisionError("float division by zero in " + where)
+    if f & FLAG_OVERFLOW:
+        return OverflowError("math range error in " + where)
+    if f & FLAG_NONFINITE:
+        return FloatingPointError("state became NaN/Inf in " + where + " - step size too large?")
+    return RuntimeError("device error in " + where)
+
+
 # --------------------------------------------------------------------------- result packing
 def pack_interval(Y, named, mech, zNo, t_end, modelId):
     """One dataPack entry (pbHomoReactor.py:3630-3678; sortResult5, solResultAnalysis.py:252-301)."""
@@ -334,10 +460,11 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
 
 
 def resolve_ivp(ivp):
-    """the reference's "default" is SciPy's LSODA (pbHomoReactor.py:3576); its other stiff choices
-    are BDF / Radau: all of them map to the device's stiff Rosenbrock stepper; the explicit SciPy
-    pairs map to the device Dormand-Prince stepper."""
-    ivp = {"default": "hip-ros4", "LSODA": "hip-ros4", "BDF": "hip-ros4", "Radau": "hip-ros4",
+    """the reference's "default" is SciPy's LSODA (pbHomoReactor.py:3576) - Adams / BDF with AUTOMATIC
+    stiffness detection: it maps to "hip-auto" (AutoStepper below: explicit Dormand-Prince while the problem is
+    not stiff, the Rosenbrock stepper when it is); SciPy's always-implicit choices BDF / Radau map to the
+    device's stiff Rosenbrock stepper, the explicit pairs to the device Dormand-Prince stepper."""
+    ivp = {"default": "hip-auto", "LSODA": "hip-auto", "BDF": "hip-ros4", "Radau": "hip-ros4",
            "RK45": "hip-rk45", "RK23": "hip-rk45", "DOP853": "hip-rk45"}.get(ivp, ivp)
     if ivp not in DEVICE_IVPS:
         raise ValueError("`ivp` must be one of %s, 'default' or a SciPy method name (got %r)"
@@ -387,6 +514,28 @@ def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=Non
     dev = N2Device(mech, ens.rows, zNo, fp32=fp32, block=block, npt=npt, defines={**defs, **ens.member_defines},
                    specialize=False, code=ens.code, features=features)
     return dev, ens.named, ens.IV
+
+
+def open_auto(mech, inputs, zNo, pack, init, sync, fp32, defines, block=None, npt=None):
+    """The two devices of ivp "hip-auto" (explicit pair in its on-chip geometry, Rosenbrock family) behind one
+    AutoStepper; an explicit `block` / `nodes-per-thread` of the solver-config applies to the explicit device."""
+    if block is None:
+        b45, n45, d45 = rk45_geometry(mech.V, zNo, fp32)
+    else:
+        b45, n45, d45 = block, npt, {}
+    dev45, named_local, IV = open_members(mech, inputs, zNo, pack, init, sync, fp32=fp32, block=b45, npt=n45,
+                                          defines={**(defines or {}), **d45})
+    def make_ros4():
+        return open_members(mech, inputs, zNo, pack, init, sync, fp32=fp32, block=ros4_block(mech.V, zNo, fp32),
+                            npt=1, defines=defines, features=("ros4",))[0]
+    if sync is None:
+        return AutoStepper(dev45, make_ros4), named_local, IV       # built only if the problem turns out stiff
+    try:        # multi-rank: creation involves collectives and the ranks may decide differently -> build it now
+        devr = make_ros4()
+    except Exception:
+        dev45.close()
+        raise
+    return AutoStepper(dev45, devr), named_local, IV
 
 
 def finish_stats(stats, ivp, n_members, tNo, zNo, jacobian_evals):
@@ -441,6 +590,8 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
             dev.multistep(y, abs(t1 - t0)/n, n, "PreCorr3" if ivp == "AM" else "AdBash3", t0)
             stats["steps"] += n
             stats["rhs_evals"] += (2*n + 6) if ivp == "AM" else (n + 8)
+        elif ivp == "hip-auto":
+            dev.advance(y, t0, t1, cfg)
         elif ivp == "hip-ros4":
             # first interval: h0 for every reactor; later ones RESUME (h0 < 0): each reactor starts from
             # the step its own controller proposed at the end of the previous interval (stats.h_last)
@@ -462,14 +613,20 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
             except Exception as e:          # noqa: BLE001 - re-raised on every rank by agree()
                 err = e
             sync.agree(err)
-        if ivp in ("hip-rk45", "hip-ros4"):
+        if ivp in ("hip-rk45", "hip-ros4", "hip-auto"):
             st = dev.rk45_stats()
             stats["accepted"] = st["accepted"] if stats["accepted"] is None else stats["accepted"] + st["accepted"]
             stats["rejected"] = st["rejected"] if stats["rejected"] is None else stats["rejected"] + st["rejected"]
         on_interval(i, t1, y.cpu().numpy().astype(np.float64))
+    if ivp == "hip-auto":
+        stats["method-per-interval"] = list(dev.choices)
     if sync is not None:
-        return gather_stats(stats, sync, ivp, tNo, zNo, dev.jacobian_evals)
-    return finish_stats(stats, ivp, n_members, tNo, zNo, dev.jacobian_evals)
+        stats = gather_stats(stats, sync, ivp, tNo, zNo, dev.jacobian_evals)
+    else:
+        stats = finish_stats(stats, ivp, n_members, tNo, zNo, dev.jacobian_evals)
+    if ivp == "hip-auto":
+        stats["rhs_evals"] = dev.rhs_evals          # includes the probe and any abandoned explicit attempt
+    return stats
 
 
 def run_n2(modelInput, members_inputs=None):
@@ -498,9 +655,13 @@ def run_n2(modelInput, members_inputs=None):
     if ivp == "hip-rk45" and block is None:
         block, npt, geo_defs = rk45_geometry(mech.V, zNo, fp32)
         defines.update(geo_defs)
-    dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants, plan.initial_state, sync,
-                                        fp32=fp32, block=block, npt=npt, defines=defines,
-                                        features=("ros4",) if ivp == "hip-ros4" else ())
+    if ivp == "hip-auto":
+        dev, named_local, IV = open_auto(mech, inputs, zNo, plan.member_constants, plan.initial_state, sync, fp32,
+                                         defines, block, npt)
+    else:
+        dev, named_local, IV = open_members(mech, inputs, zNo, plan.member_constants, plan.initial_state, sync,
+                                            fp32=fp32, block=block, npt=npt, defines=defines,
+                                            features=("ros4",) if ivp == "hip-ros4" else ())
     # the process that returns the results (rank 0, or the only one) packs EVERY member
     packer = sync is None or sync.rank == 0
     if sync is None:

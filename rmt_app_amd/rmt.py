@@ -6,7 +6,8 @@ Only the hot path named in BASELINE.json is implemented: ``model == "N2"`` (dyna
 packed-bed reactor), plus the "next" rows of SURVEY.md section 8(f): ``"N1"`` (steady state) and ``"M2"``
 (the dimensional dynamic model).  ``solver-config.ivp`` selects the device integrator: ``"hip-ros4"`` (stiff
 Rosenbrock), ``"hip-rk4"``, ``"hip-rk45"``, ``"AM"`` (the reference's PreCorr3); ``"default"`` - LSODA
-in the reference, pbHomoReactor.py:3576 - and SciPy's stiff method names map to ``"hip-ros4"``.  Any other model id raises - the reference silently returns None there
+in the reference, pbHomoReactor.py:3576, i.e. automatic stiffness detection - maps to ``"hip-auto"`` (explicit
+pair while the problem is not stiff, Rosenbrock when it is); SciPy's implicit method names map to ``"hip-ros4"``.  Any other model id raises - the reference silently returns None there
 (rmtCore.py:90-127), which is not a behaviour worth mirroring for unsupported models.
 """
 import timeit

@@ -34,6 +34,11 @@ DEVICE_DEFAULTS = {
     "ros4-rtol": 1e-6,
     "ros4-atol": 1e-9,
     "ros4-h0": 1e-5,
+    # ivp "hip-auto" (what "default" / "LSODA" resolve to): explicit phase of the automatic stiff / non-stiff choice
+    "auto-rk45-rtol": 1e-8,
+    "auto-rk45-atol": 1e-11,
+    "auto-probe-steps": 40,          # RK45 steps spent on finding out how stiff the interval is
+    "auto-max-explicit-steps": 2000,  # estimated RK45 steps per output interval above which the stiff stepper takes over
     "n1-rtol": 1e-8,     # the steady profile is one lane's worth of work: afford tight defaults
     "n1-atol": 1e-11,
 }

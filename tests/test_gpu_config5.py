@@ -216,3 +216,39 @@ def test_full_size_ensemble_2048_members_vs_oracle():
         assert np.max(np.abs(got[e].reshape(7, N) - want)/scale) < 1e-11, e
     assert np.max(np.abs(got[0] - got[1])) > 1e-9
     dev.close()
+
+
+@pytest.mark.parametrize("name,expect", [("dme_nb", "ros4"), ("syn12", "rk45"), ("ch4", "rk45")])
+def test_default_ivp_chooses_the_integrator_like_lsoda(name, expect):
+    """The reference's default integrator is LSODA - automatic stiff / non-stiff switching (pbHomoReactor.py:3576).
+    An UNMODIFIED modelInput (ivp = "default") probes with the explicit pair and settles on the Rosenbrock stepper
+    for the stiff DME case, on Dormand-Prince for the 12-species and CH4 mechanisms (which the stiff stepper
+    integrates 30x slower: 13 x 13 node Jacobians for a problem that is not stiff) - and meets the 1e-6 outlet
+    requirement against the reference's tight runs either way."""
+    g = np.load(os.path.join(G, "g4_tight_%s.npz" % {"dme_nb": "dme_nb_lsoda", "syn12": "syn12_bdf", "ch4": "ch4_bdf"}[name]))
+    mi = INP.ALL_N2_INPUTS[name]()
+    assert mi["solver-config"]["ivp"] == "default"
+    mi["solver-config"]["quiet"] = True
+    res = rmtExe(mi)["resModel"]
+    st = res["device-stats"]
+    assert st["method-per-interval"] == [expect]*5, st["method-per-interval"]
+    assert outlet_rel(res["dataPack"], g) < 1e-6
+    assert st["rhs_evals"] > 0 and st["steps"] > 0
+
+
+def test_auto_switches_to_the_stiff_stepper_when_the_bed_heats_up():
+    """The DME transient is mild at first (the explicit pair's stability limit is ~1e-5 s on the cold bed) and
+    stiff once the bed heats up (~5e-6 s at zNo = 20): with 20 ms output intervals the automatic choice starts
+    explicit, finds an interval too expensive (> 2000 steps) and hands over to the stiff stepper for good."""
+    mi = INP.dme_notebook_input(period=0.2)
+    mi["solver-config"].update({"quiet": True, "tNo": 10})
+    res = rmtExe(mi)["resModel"]
+    seq = res["device-stats"]["method-per-interval"]
+    assert seq[0] == "rk45" and seq[-1] == "ros4", seq
+    k = seq.index("ros4")
+    assert all(m == "ros4" for m in seq[k:]), seq
+    ref = INP.dme_notebook_input(ivp="hip-ros4", period=0.2)
+    ref["solver-config"].update({"quiet": True, "tNo": 10, "rtol": 1e-8, "atol": 1e-11})
+    a = res["dataPack"][-1]["dataYs"]
+    b = rmtExe(ref)["resModel"]["dataPack"][-1]["dataYs"]
+    assert np.max(np.abs(a - b)/np.abs(b)) < 2e-6

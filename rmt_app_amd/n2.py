@@ -574,9 +574,7 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
     tNo = len(opTSpan) - 1
     stats = {"steps": 0, "rhs_evals": 0, "node_steps": 0, "accepted": None, "rejected": None}
     _progress(0, tNo + 1, quiet)
-    for i in range(tNo):
-        t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
-        _progress(i + 1, tNo + 1, quiet)
+    def launch(i, t0, t1):
         if ivp == "hip-rk4":
             dt_req = float(cfg.get('dt', DEVICE_DEFAULTS['rk4-dt']))
             n = max(1, int(round((t1 - t0)/dt_req)))
@@ -604,13 +602,18 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
             dev.rk45(y, t0, t1, float(cfg.get('rtol', DEVICE_DEFAULTS['rk45-rtol'])),
                      float(cfg.get('atol', DEVICE_DEFAULTS['rk45-atol'])), h0 if i == 0 else -h0,
                      int(cfg.get('max-steps', DEVICE_DEFAULTS['rk45-max-steps'])))
+        dev.raise_on_flags()
+
+    for i in range(tNo):
+        t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
+        _progress(i + 1, tNo + 1, quiet)
         if sync is None:
-            dev.raise_on_flags()
-        else:
+            launch(i, t0, t1)
+        else:                                   # whatever goes wrong on one rank is raised on every rank
             err = None
             try:
-                dev.raise_on_flags()
-            except Exception as e:          # noqa: BLE001 - re-raised on every rank by agree()
+                launch(i, t0, t1)
+            except Exception as e:              # noqa: BLE001 - re-raised on every rank by agree()
                 err = e
             sync.agree(err)
         if ivp in ("hip-rk45", "hip-ros4", "hip-auto"):

@@ -119,6 +119,9 @@ const char* rmt_n2_kernel_template(void);
  * PyTorch bundles, otherwise /opt/rocm's; both report version 9.0 but generate different code): part of the key
  * of any code-object cache */
 const char* rmt_n2_hiprtc_path(void);
+/* the options rmt_n2_compile adds to every compilation besides --offload-arch and `extra_opts` (an `extra_opts`
+ * that sets -mllvm ...machine-licm... itself replaces the default of that switch): the other part of a cache key */
+const char* rmt_n2_compile_options(void);
 
 int rmt_n2_create(const rmt_n2_plan* plan, rmt_n2_handle** out);
 void rmt_n2_destroy(rmt_n2_handle* h);

@@ -96,6 +96,13 @@ extern "C" const char* rmt_n2_hiprtc_path(void) {
     return "";
 }
 extern "C" void rmt_n2_free(void* p) { free(p); }
+// Options every kernel is compiled with.  -disable-machine-licm: the machine-level loop-invariant code motion
+// hoists the materialisation of fp64 literals (s_mov pairs) and compare masks out of the time-step loop into
+// SGPRs, runs out of them and spills to VGPR lanes (v_writelane / v_readlane, full VALU slots) and, for the
+// VGPR-resident ones, to scratch; without it the step loop of rmt_n2_rk45_reg has 2135 instead of 2294 VALU
+// instructions and 4 instead of 13 scratch accesses (measured: +16 %; rmt_n2_rk4_reg +4 %, profiles/round2_issue_model.md).
+static const char* const k_default_opts = "-O3 -std=c++17 -mllvm -disable-machine-licm";
+extern "C" const char* rmt_n2_compile_options(void) { return k_default_opts; }
 
 extern "C" int rmt_n2_compile(const char* source, const char* arch, const char* extra_opts,
                               void** code, size_t* code_size, char** log) {
@@ -107,9 +114,10 @@ extern "C" int rmt_n2_compile(const char* source, const char* arch, const char* 
     hiprtcResult r = hiprtcCreateProgram(&prog, source, "rmt_n2_generated.hip", 0, nullptr, nullptr);
     if (r != HIPRTC_SUCCESS) return fail("hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::string archopt = std::string("--offload-arch=") + (arch && *arch ? arch : "gfx950");
-    std::vector<std::string> store = {archopt, "-O3", "-std=c++17"};
-    if (extra_opts && *extra_opts) {
-        std::string s(extra_opts);
+    std::vector<std::string> store = {archopt};
+    // an -mllvm switch may be given only once: a caller that sets machine-licm itself replaces the default
+    const bool own_licm = extra_opts && strstr(extra_opts, "machine-licm");
+    for (std::string s : {std::string(own_licm ? "-O3 -std=c++17" : k_default_opts), std::string(extra_opts ? extra_opts : "")}) {
         size_t pos = 0;
         while (pos < s.size()) {
             size_t sp = s.find(' ', pos);

@@ -67,6 +67,7 @@ def lib():
     L.rmt_n2_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rmt_n2_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rmt_n2_hiprtc_path.restype = cp
+    L.rmt_n2_compile_options.restype = cp
     if L.rmt_n2_abi_version() != ABI_VERSION:
         raise RmtN2Error("librmt_n2.so ABI %d != binding ABI %d" % (L.rmt_n2_abi_version(), ABI_VERSION))
     _lib = L
@@ -113,7 +114,9 @@ def hiprtc_tag():
             size = os.path.getsize(path)
         except OSError:
             size = 0
-        _RTC_TAG = hashlib.sha256(("%s:%d" % (path, size)).encode()).hexdigest()[:8]
+        # ... and from the options the library compiles with by default
+        _RTC_TAG = hashlib.sha256(("%s:%d:%s" % (path, size, lib().rmt_n2_compile_options().decode())).encode()
+                                  ).hexdigest()[:8]
     return _RTC_TAG
 
 

@@ -43,7 +43,7 @@ struct rmt_n2_handle {
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
                   f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr, f_n1 = nullptr,
-                  f_ros4_chain = nullptr;
+                  f_ros4_chain = nullptr, f_rk45_chain = nullptr;
     unsigned long long* d_rings = nullptr;   // tagged-word links of the chained stiff stepper: rings, decision slots, abort words
     size_t ring_bytes = 0;
     double* d_members1 = nullptr;
@@ -199,6 +199,8 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         h->f_rk45_reg = nullptr;
     if (hipModuleGetFunction(&h->f_rk45_mem, h->module, "rmt_n2_rk45_mem") != hipSuccess)
         h->f_rk45_mem = nullptr;
+    if (hipModuleGetFunction(&h->f_rk45_chain, h->module, "rmt_n2_rk45_chain") != hipSuccess)
+        h->f_rk45_chain = nullptr;
     if (hipModuleGetFunction(&h->f_multistep, h->module, "rmt_n2_multistep_mem") != hipSuccess)
         h->f_multistep = nullptr;
     if (hipModuleGetFunction(&h->f_rk4_chain, h->module, "rmt_n2_rk4_chain") != hipSuccess)
@@ -399,6 +401,27 @@ extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, doub
                         (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms, (void*)&stats,
                         (void*)&h->d_flags};
         return launch(h, h->f_rk45_reg, args);
+    }
+    // Reactors longer than one workgroup's on-chip capacity: C chunks per reactor on C CUs, T teams, every
+    // workgroup resident (rmt_n2_rk45_chain; the code object has it when the on-chip slots fit the geometry).
+    {
+        const int W = h->block * h->npt;
+        int C = (h->N + W - 1) / W;
+        const bool can_chain = h->f_rk45_chain && C >= 2 && C <= h->n_cus && C <= RMT_N2_MAX_CHUNKS;
+        if (h->mode == 3 && !can_chain)
+            return fail("chained rk45 needs the on-chip stepper in the code object and 2 <= chunks (%d) <= %d", C,
+                        h->n_cus < RMT_N2_MAX_CHUNKS ? h->n_cus : RMT_N2_MAX_CHUNKS);
+        if (can_chain && (h->mode == 3 || h->mode == 0)) {
+            int T = h->n_cus / C;
+            if (T > h->E) T = h->E;
+            unsigned long long* decision = nullptr;
+            unsigned* abort_words = nullptr;
+            if (ensure_rings(h, T, C, &decision, &abort_words)) return 1;
+            void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T, (void*)&t0,
+                            (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms, (void*)&stats,
+                            (void*)&h->d_flags, (void*)&h->d_rings, (void*)&decision, (void*)&abort_words};
+            return launch(h, h->f_rk45_chain, args, T * C);
+        }
     }
     if (!h->f_rk45_mem) return fail("code object has no rk45 kernel");
     if (ensure_work(h, 10)) return 1;      // K_1..K_7 (when they do not fit in LDS), y_new, K_1/K_7 of the FSAL swap

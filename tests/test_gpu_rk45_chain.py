@@ -1,0 +1,114 @@
+"""GPU tests of rmt_n2_rk45_chain: the adaptive on-chip stepper with one reactor cut into chunks on several
+CUs (tagged-word links per RK stage, error norm down the chain, decision slot).  Checked against the oracle's
+controller (oracle/n2_oracle.py rk45) at sizes it finishes in seconds, against the memory-resident kernel
+of the same library at the sizes the chain is for, and for its failure contract (a stuck producer)."""
+import numpy as np
+import pytest
+
+import inputs as INP
+from oracle import n2_oracle as O
+from rmt_app_amd import plan
+from rmt_app_amd.lowering import FLAG_STEP
+from rmt_app_amd.n2 import N2Device, rk45_geometry
+
+pytestmark = pytest.mark.gpu
+
+
+def _members(name, N, temps):
+    mech = plan.Mechanism(INP.ALL_N2_INPUTS[name]())
+    rows, ivs, mis = [], [], []
+    for T in temps:
+        mi = INP.ALL_N2_INPUTS[name]()
+        mi["operating-conditions"]["temperature"] = T
+        nm, row = plan.member_constants(mi, mech, N)
+        rows.append(row), ivs.append(plan.initial_state(nm, mech, N)), mis.append(mi)
+    return mech, np.array(rows), np.array(ivs), mis
+
+
+def _rel(a, b, E, V, N):
+    a, b = a.reshape(E, V, N), b.reshape(E, V, N)
+    scale = np.max(np.abs(b), axis=2, keepdims=True)
+    scale[scale == 0] = 1.0
+    return float(np.max(np.abs(a - b)/scale))
+
+
+def test_chain_vs_oracle_controller_small_chunks():
+    """4 chunks of 64 nodes (N = 200: the last chunk is ragged), two reactors with their own step sequences:
+    accept / reject history of the oracle's controller, end state within 50 rtol."""
+    N, t1, rtol, atol, h0 = 200, 4e-3, 1e-6, 1e-9, 1e-6
+    mech, rows, IV, mis = _members("dme_nb", N, (523, 538))
+    dev = N2Device(mech, rows, N, block=64, npt=1, defines={"RMT_RK45_LDS": "2"})
+    dev.set_mode("chain")
+    y = dev.to_device(IV)
+    dev.rk45(y, 0.0, t1, rtol, atol, h0, 10**7)
+    assert not dev.status().any()
+    st = dev.rk45_stats()
+    got = y.cpu().numpy()
+    for e, mi in enumerate(mis):
+        pr = O.setup_n2(mi, N)
+        want, ost = O.rk45(O.make_rhs_vec(pr), 0.0, t1, pr["IV"], rtol, atol, h0)
+        assert st["t_end"][e] == t1
+        assert abs(int(st["accepted"][e]) - ost["accepted"]) <= max(2, 0.02*ost["accepted"]), (e, st, ost)
+        assert abs(int(st["rejected"][e]) - ost["rejected"]) <= max(3, 0.05*ost["accepted"]), (e, st, ost)
+        assert _rel(got[e], want, 1, mech.V, N) < 50*rtol
+    dev.close()
+
+
+@pytest.mark.parametrize("name,N,E,t1", [("dme_nb", 2500, 5, 3e-3), ("syn12", 1024, 6, 3e-2), ("dme_nb", 2048, 300, 1e-3)])
+def test_chain_matches_memory_resident_kernel(name, N, E, t1):
+    """The geometry rmtExe picks for reactors beyond one workgroup (rk45_geometry): same step sequences and the
+    same end state (rounding level) as rmt_n2_rk45_mem; the third case has more reactors than teams
+    (2 chunks -> 128 teams for 300 reactors), so every team integrates several reactors one after the other."""
+    mech, rows, IV, _ = _members(name, N, [523 + (e % 9) if name == "dme_nb" else 600 + 3*(e % 9) for e in range(E)])
+    block, npt, defs = rk45_geometry(mech.V, N)
+    assert block*npt < N                         # the chained geometry
+    out, stats = {}, {}
+    for mode in ("mem", "chain"):
+        dev = N2Device(mech, rows, N, block=block, npt=npt, defines=defs)
+        dev.set_mode(mode if mode == "chain" else "mem")
+        y = dev.to_device(IV)
+        dev.rk45(y, 0.0, 0.4*t1, 1e-6, 1e-9, 1e-6, 10**7)
+        dev.rk45(y, 0.4*t1, t1, 1e-6, 1e-9, -1e-6, 10**7)      # resumed: every reactor from its own h_last
+        assert not dev.status().any(), mode
+        out[mode], stats[mode] = y.cpu().numpy(), dev.rk45_stats()
+        dev.close()
+    assert np.all(stats["chain"]["t_end"] == t1)
+    assert np.array_equal(stats["chain"]["accepted"], stats["mem"]["accepted"])
+    assert np.array_equal(stats["chain"]["rejected"], stats["mem"]["rejected"])
+    assert _rel(out["chain"], out["mem"], E, mech.V, N) < 1e-11
+
+
+def test_auto_mode_chains_long_reactors():
+    """mode 0 (what rmtExe uses): a code object with the on-chip stepper chains a reactor that does not fit one
+    workgroup; the result is the chained kernel's bit for bit."""
+    N, E, t1 = 2100, 3, 2e-3
+    mech, rows, IV, _ = _members("dme_nb", N, (523, 530, 541))
+    block, npt, defs = rk45_geometry(mech.V, N)
+    res = {}
+    for mode in ("auto", "chain"):
+        dev = N2Device(mech, rows, N, block=block, npt=npt, defines=defs)
+        dev.set_mode(mode)
+        y = dev.to_device(IV)
+        dev.rk45(y, 0.0, t1, 1e-6, 1e-9, 1e-6, 10**7)
+        assert not dev.status().any()
+        res[mode] = y.cpu().numpy()
+        dev.close()
+    assert np.array_equal(res["auto"], res["chain"])
+
+
+def test_chain_stuck_producer_ends_with_step_flag_on_every_member():
+    """One chunk stops sending its stage records (debug define): the consumer times out, sets the team's abort
+    word, every workgroup drains and the launch ENDS; the reactor in flight and the ones the team never
+    started carry RMT_FLAG_STEP."""
+    N, E = 1000, 300                     # 4 chunks of 256 nodes; 64 teams -> 4-5 reactors per team
+    mech, rows, IV, _ = _members("dme_nb", N, [523 + (e % 5) for e in range(E)])
+    dev = N2Device(mech, rows, N, block=128, npt=2, specialize=False,
+                   defines={"RMT_RK45_LDS": "2", "RMT_CHAIN_SPINS": "4096", "RMT_CHAIN_TEST_STALL_CHUNK": "1",
+                            "RMT_CHAIN_TEST_STALL_FROM": "20"})
+    dev.set_mode("chain")
+    y = dev.to_device(IV)
+    dev.rk45(y, 0.0, 1e-3, 1e-6, 1e-9, 1e-6, 10**7)
+    flags = dev.status()                 # returns: the launch did not hang
+    assert np.all(flags & FLAG_STEP), flags[:8]
+    assert np.all(np.isfinite(y.cpu().numpy()))      # the last accepted states, not garbage
+    dev.close()

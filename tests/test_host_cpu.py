@@ -436,11 +436,20 @@ def test_rk45_geometry_and_lds_budget():
     assert rk45_geometry(7, 1024) == (512, 2, {"RMT_RK45_LDS": "2"})
     assert rk45_geometry(7, 20) == (64, 1, {"RMT_RK45_LDS": "2"})
     assert rk45_geometry(13, 512) == (256, 2, {"RMT_RK45_LDS": "2"})
-    assert rk45_geometry(7, 4096) == (rk45_block(7, 4096), 1, {})
-    assert rk45_geometry(13, 1024) == (rk45_block(13, 1024), 1, {})
+    # longer reactors (model N2): chunks of the on-chip size on several CUs ...
+    assert rk45_geometry(7, 4096) == (512, 2, {"RMT_RK45_LDS": "2"})
+    assert rk45_geometry(13, 1024) == (256, 2, {"RMT_RK45_LDS": "2"})
+    assert rk45_geometry(7, 16384) == (512, 2, {"RMT_RK45_LDS": "2"})
+    # ... unless that takes more chunks than a team may have, or the model has no chained stepper (M2)
+    assert rk45_geometry(7, 1024*65) == (rk45_block(7, 1024*65), 1, {})
+    assert rk45_geometry(7, 4096, chain=False) == (rk45_block(7, 4096), 1, {})
+    assert rk45_geometry(13, 1024, chain=False) == (rk45_block(13, 1024), 1, {})
     for V, N in ((7, 1024), (13, 512), (4, 700), (8, 1024)):
         block, npt, defs = rk45_geometry(V, N)
         assert block*npt >= N and int(defs["RMT_RK45_LDS"])*V*block*npt*8 <= 136*1024
+    for V, N in ((7, 4096), (13, 1024), (7, 16384)):
+        block, npt, defs = rk45_geometry(V, N)
+        assert int(defs["RMT_RK45_LDS"])*V*block*npt*8 <= 136*1024
 
 
 def test_device_stats_totals():

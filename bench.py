@@ -198,18 +198,21 @@ def single_reactor_4096(mech, inputs):
 def adaptive_rk45(mech, rows, IV, n_nodes):
     """BASELINE configs[4]: adaptive Dormand-Prince RK45 with per-reactor step control on the device
     (rmt_n2_rk45_reg, on chip) - accepted node-steps/s of this rank's sweep over 8 ms of reactor time after
-    a warm-up interval, and the 12-species / 8-reaction mechanism on 64 x 512 nodes."""
+    a warm-up interval, and the 12-species / 8-reaction mechanism on 64 x 512 nodes (one workgroup per
+    reactor) and on this rank's share of configs[4], 256 x 1024 nodes (rmt_n2_rk45_chain: two chunks per
+    reactor)."""
     import inputs as INP
     from rmt_app_amd import plan
     from rmt_app_amd.n2 import N2Device, rk45_geometry
     out = {}
     for tag, mech_, rows_, IV_, N, t1 in (("dme_%dx%d" % (len(rows), n_nodes), mech, rows, IV, n_nodes, 8e-3),
-                                          ("syn12_64x512", None, None, None, 512, 0.1)):
+                                          ("syn12_64x512", None, 64, None, 512, 0.1),
+                                          ("syn12_256x1024", None, 256, None, 1024, 0.05)):
         if mech_ is None:
             mi = INP.syn12_input()
             mech_ = plan.Mechanism(mi)
             nm, row = plan.member_constants(mi, mech_, N)
-            rows_, IV_ = np.tile(row, (64, 1)), np.tile(plan.initial_state(nm, mech_, N), (64, 1))
+            rows_, IV_ = np.tile(row, (rows_, 1)), np.tile(plan.initial_state(nm, mech_, N), (rows_, 1))
         block, npt, defs = rk45_geometry(mech_.V, N)
         dev = N2Device(mech_, rows_, N, block=block, npt=npt, defines=defs)
         y = dev.to_device(IV_)
@@ -222,7 +225,9 @@ def adaptive_rk45(mech, rows, IV, n_nodes):
         out[tag] = {"accepted_node_steps_per_s": N*float(st["accepted"].sum())/(ms*1e-3), "kernel_ms": ms,
                     "accepted_per_reactor_median": int(np.median(st["accepted"])),
                     "rejected_max": int(st["rejected"].max()), "rtol": 1e-6, "atol": 1e-9,
-                    "kernel": "rmt_n2_rk45_%s block=%d npt=%d" % ("reg" if defs else "mem", block, npt), "flags_ok": ok}
+                    "kernel": "rmt_n2_rk45_%s block=%d npt=%d" % (
+                        ("reg" if block*npt >= N else "chain[%d]" % -(-N//(block*npt))) if defs else "mem", block, npt),
+                    "flags_ok": ok}
     return out
 
 
@@ -280,6 +285,9 @@ def prebuild(members=MEMBERS_PER_GPU, n_nodes=N_NODES):
     _, rs = plan.member_constants(INP.syn12_input(), ms, 512)
     block, npt, defs = rk45_geometry(ms.V, 512)
     keys.append(precompile(ms, np.tile(rs, (64, 1)), 512, block=block, npt=npt, defines=defs))
+    _, rs = plan.member_constants(INP.syn12_input(), ms, 1024)
+    block, npt, defs = rk45_geometry(ms.V, 1024)
+    keys.append(precompile(ms, np.tile(rs, (256, 1)), 1024, block=block, npt=npt, defines=defs))
     # time_to_solution
     keys.append(precompile(mech, rows, n_nodes, block=256, npt=1, features=("ros4",)))
     return keys

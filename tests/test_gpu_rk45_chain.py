@@ -78,6 +78,26 @@ def test_chain_matches_memory_resident_kernel(name, N, E, t1):
     assert _rel(out["chain"], out["mem"], E, mech.V, N) < 1e-11
 
 
+def test_chain_fp32_build_agrees_with_memory_resident_kernel():
+    """`dtype: fp32` code objects (state and kinetics in float, pressure scan in fp64) have the chained stepper
+    too: same number of steps within a few, end state within single-precision noise of the memory-resident one."""
+    N, E, t1 = 2500, 4, 2e-3
+    mech, rows, IV, _ = _members("dme_nb", N, (523, 528, 533, 538))
+    block, npt, defs = rk45_geometry(mech.V, N, fp32=True)
+    assert block*npt < N
+    out, stats = {}, {}
+    for mode in ("mem", "chain"):
+        dev = N2Device(mech, rows, N, fp32=True, block=block, npt=npt, defines=defs)
+        dev.set_mode(mode)
+        y = dev.to_device(IV)
+        dev.rk45(y, 0.0, t1, 1e-4, 1e-7, 1e-6, 10**7)
+        assert not dev.status().any(), mode
+        out[mode], stats[mode] = y.cpu().numpy().astype(np.float64), dev.rk45_stats()
+        dev.close()
+    assert np.all(np.abs(stats["chain"]["accepted"] - stats["mem"]["accepted"]) <= 3)
+    assert _rel(out["chain"], out["mem"], E, mech.V, N) < 2e-3
+
+
 def test_auto_mode_chains_long_reactors():
     """mode 0 (what rmtExe uses): a code object with the on-chip stepper chains a reactor that does not fit one
     workgroup; the result is the chained kernel's bit for bit."""

@@ -75,7 +75,7 @@ extern "C" {
  * Every entry point taking a handle runs on the device that was current at rmt_n2_create and
  * restores the caller's current device before returning. */
 
-/* chained stiff stepper (rmt_n2_ros4 with one reactor over several CUs): ring depth of a tagged-word link
+/* chained steppers (rmt_n2_ros4 / rmt_n2_rk45 / rmt_n2_rk4 with one reactor over several CUs): ring depth of a tagged-word link
  * (= RMT_RING of n2_kernels.inc) and the largest number of chunks one reactor is cut into */
 #define RMT_N2_RING 512
 #define RMT_N2_MAX_CHUNKS 64
@@ -149,9 +149,10 @@ int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout
 /* copies the E flag words to host memory (synchronises the stream) and clears them on device */
 int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
 /* which stepper rmt_n2_rk4 / rk45 / ros4 use: 0 = auto (on-chip if N fits one workgroup, else chained
- * workgroups, else memory; ros4: one workgroup per reactor unless the ensemble leaves more than half of
- * the CUs idle, then the reactor is chained over several), 1 = on-chip single workgroup,
- * 2 = one workgroup per reactor with the state in memory, 3 = chained workgroups */
+ * workgroups - rk4: any model; rk45: model N2 code objects that hold the on-chip stepper, at most
+ * RMT_N2_MAX_CHUNKS chunks of block*nodes_per_thread nodes - else memory; ros4: one workgroup per reactor
+ * unless the ensemble leaves more than half of the CUs idle, then the reactor is chained over several),
+ * 1 = on-chip single workgroup, 2 = one workgroup per reactor with the state in memory, 3 = chained workgroups */
 int rmt_n2_set_mode(rmt_n2_handle* h, int mode);
 /* timing of the last rk4/rk45/rhs launch in ms (HIP events on the handle's stream; synchronises) */
 int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms);

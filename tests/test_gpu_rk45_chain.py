@@ -132,3 +132,25 @@ def test_chain_stuck_producer_ends_with_step_flag_on_every_member():
     assert np.all(flags & FLAG_STEP), flags[:8]
     assert np.all(np.isfinite(y.cpu().numpy()))      # the last accepted states, not garbage
     dev.close()
+
+
+def test_rmtexe_rk45_on_a_mesh_beyond_one_workgroup():
+    """rmtExe with ivp 'RK45' at zNo = 1100: the host picks the on-chip geometry and the library chains two chunks
+    per reactor; the five output times agree with the fixed-step device RK4 (dt = 2e-6 s, itself 5e-11 from the
+    reference's tight LSODA run at zNo = 20) to the tolerance asked for."""
+    from rmt_app_amd import rmtExe
+    packs = {}
+    for ivp, extra in (("hip-rk4", {"dt": 2e-6}), ("RK45", {"rtol": 1e-8, "atol": 1e-11})):
+        mi = INP.dme_notebook_input(ivp=ivp)
+        mi["solver-config"].update({"quiet": True, "zNo": 1100, **extra})
+        res = rmtExe(mi)
+        packs[ivp] = res["resModel"]["dataPack"]
+        if ivp == "RK45":
+            st = res["resModel"]["device-stats"]
+            assert st["steps"] > 1000 and st["rejected"] is not None
+    worst = 0.0
+    for k in range(5):
+        a, b = packs["RK45"][k]["dataYs"], packs["hip-rk4"][k]["dataYs"]
+        assert a.shape == b.shape == (7, 1100)
+        worst = max(worst, float(np.max(np.abs(a - b)/np.maximum(np.abs(b), 1e-300))))
+    assert worst < 1e-6, worst

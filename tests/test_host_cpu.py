@@ -499,3 +499,17 @@ def test_traffic_record_is_keyed_by_kernel_digest():
     assert bench.tracked_traffic(dig, ent["members"] + 1, ent["nodes"]) == (None, None)
     ref = bench.reference_cpu_rate(1024)
     assert 100 < ref["value"] < 5000 and ref["cores"] == 1
+
+
+def test_default_compile_options_and_caller_override():
+    """rmt_n2_compile adds the library's default options (part of the cache key through hipbind.hiprtc_tag); an
+    `extra_opts` that sets the machine-LICM switch itself replaces the default instead of repeating it (an -mllvm
+    switch may be given once)."""
+    from rmt_app_amd import hipbind
+    opts = hipbind.lib().rmt_n2_compile_options().decode()
+    assert "-O3" in opts and "-disable-machine-licm" in opts
+    src = 'extern "C" __global__ void k(double* a) { for (int i = 0; i < 8; ++i) a[i] = a[i]*1.25 + 3.0; }'
+    blob, _ = hipbind.compile_source(src)
+    again, _ = hipbind.compile_source(src, extra_opts="-mllvm -disable-machine-licm")
+    assert blob[:4] == b"\x7fELF" and again[:4] == b"\x7fELF"
+    assert len(hipbind.hiprtc_tag()) == 8

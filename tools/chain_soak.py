@@ -56,3 +56,38 @@ for N, E, reps in ((4096, 1, 10), (1024, 40, 10), (16384, 2, 3)):
                     and float(np.max(np.abs(out - ref)/np.maximum(np.abs(ref), 1e-300))) < 1e-6
     print("ros4 chain soak N=%d E=%d x%d: %s (accepted %d)" % (N, E, reps, "ok" if ok else "MISMATCH", int(ref_acc[0])), flush=True)
     dev.close()
+
+# chained ADAPTIVE EXPLICIT stepper: long integrations (tens of thousands of steps = hundreds of thousands of link
+# messages per chunk), one reactor over 4 / 16 chunks and ensembles with more reactors than teams; step history and
+# result must equal the memory-resident kernel's, and repeats of the chained launch must be bitwise identical
+from rmt_app_amd.n2 import rk45_geometry
+for name, N, E, t1, reps in (("dme_nb", 4096, 1, 0.05, 3), ("dme_nb", 16384, 3, 0.02, 2), ("dme_nb", 2048, 300, 0.01, 2),
+                             ("syn12", 1024, 200, 0.2, 2)):
+    mi = INP.ALL_N2_INPUTS[name]()
+    mech = plan.Mechanism(mi)
+    rows, ivs = [], []
+    for e in range(E):
+        m2 = INP.ALL_N2_INPUTS[name]()
+        m2["operating-conditions"]["temperature"] = mi["operating-conditions"]["temperature"] + (e % 11)
+        nm, row = plan.member_constants(m2, mech, N)
+        rows.append(row), ivs.append(plan.initial_state(nm, mech, N))
+    block, npt, defs = rk45_geometry(mech.V, N)
+    dev = N2Device(mech, np.array(rows), N, block=block, npt=npt, defines=defs)
+    ok, ref, ref_acc, first, ms = True, None, None, None, 0.0
+    for mode, n in (("mem", 1), ("chain", reps)):
+        dev.set_mode(mode)
+        for r in range(n):
+            y = dev.to_device(np.array(ivs))
+            dev.rk45(y, 0.0, t1, 1e-6, 1e-9, 1e-6, 10**8)
+            fl, st, out = dev.status(), dev.rk45_stats(), y.cpu().numpy()
+            if mode == "mem":
+                ref, ref_acc = out, st["accepted"].copy()
+            else:
+                ms = dev.last_kernel_ms()
+                if r == 0:
+                    first = out
+                ok = ok and not fl.any() and np.array_equal(st["accepted"], ref_acc) and np.array_equal(out, first) \
+                    and float(np.max(np.abs(out - ref)/np.maximum(np.abs(ref), 1e-30))) < 1e-6
+    print("rk45 chain soak %s N=%d E=%d x%d: %s (accepted %d..%d, %.0f ms per chained launch)" % (
+        name, N, E, reps, "ok" if ok else "MISMATCH", int(ref_acc.min()), int(ref_acc.max()), ms), flush=True)
+    dev.close()

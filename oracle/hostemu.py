@@ -70,17 +70,22 @@ class HostEmu:
         self.lib.emu_n1_rhs(u.ctypes.data, out.ctypes.data, members1.ctypes.data, E, flags.ctypes.data)
         return out, flags
 
-    def node_jac(self, y, member, N):
+    def node_jac(self, y, member, N, coupling=False):
         """(analytic, forward-difference) node Jacobians -d f_z/d y_z, each [N][V][V], of one reactor state
-        (needs a source generated with defines={"RMT_WITH_ROS4": "1"})."""
+        (needs a source generated with defines={"RMT_WITH_ROS4": "1"}); coupling=True (model M2): also the
+        (analytic, forward-difference) upwind couplings d f_r/d up_r, each [N][V]."""
         y = np.ascontiguousarray(y, dtype=self.dtype).reshape(self.V*N)
         member = np.ascontiguousarray(member, dtype=np.float64).reshape(-1)
         jan = np.zeros((N, self.V, self.V))
         jfd = np.zeros((N, self.V, self.V))
-        self.lib.emu_node_jac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lan = np.zeros((N, self.V))
+        lfd = np.zeros((N, self.V))
+        self.lib.emu_node_jac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]
         self.lib.emu_node_jac.restype = None
-        self.lib.emu_node_jac(y.ctypes.data, member.ctypes.data, N, jan.ctypes.data, jfd.ctypes.data)
-        return jan, jfd
+        self.lib.emu_node_jac(y.ctypes.data, member.ctypes.data, N, jan.ctypes.data, jfd.ctypes.data,
+                              lan.ctypes.data if coupling else None, lfd.ctypes.data if coupling else None)
+        return (jan, jfd, lan, lfd) if coupling else (jan, jfd)
 
     def rk4(self, y, members, N, h, nsteps):
         y = np.array(y, dtype=self.dtype).reshape(-1, self.V*N)

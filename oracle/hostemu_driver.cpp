@@ -104,11 +104,14 @@ extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_,
     }
 }
 
-#if RMT_WITH_ROS4 && RMT_MODEL == 0
+#if RMT_WITH_ROS4
 // Analytic node Jacobian of the stiff stepper (rmt_node_jac) next to the forward-difference one it
 // replaces, for every node of ONE reactor state: jan / jfd are [N][V][V] = -d f_r / d y_c at the
 // frozen (P, upstream state) the RHS evaluation sees.
-extern "C" void emu_node_jac(const real* y, const double* member, int N, double* jan, double* jfd) {
+extern "C" void emu_node_jac(const real* y, const double* member, int N, double* jan, double* jfd,
+                             double* lan, double* lfd) {      // lan / lfd: [N][V], model M2 only (may be null)
+    (void)lan;
+    (void)lfd;
     RmtMember m;
     rmt_load_member(member, m);
     rmt_noflags_t nof;
@@ -125,7 +128,23 @@ extern "C" void emu_node_jac(const real* y, const double* member, int N, double*
         const auto a0 = rmt_node_pre(m, ys, nd);
         rmt_node_post(m, nd, ys, up, P, k, nof);
         real a[RMT_V][RMT_V], r[RMT_R];
+#if RMT_MODEL == 0
         rmt_node_jac(m, nd, ys, P, a, r, nof);
+#else
+        real lco[RMT_V], kpu[RMT_V];
+        rmt_node_jac(m, nd, ys, up, P, a, r, lco, nof);
+        if (lfd) {                                  // d f_r / d up_r next to its forward difference
+            for (int c = 0; c < RMT_V; ++c) {
+                real upp[RMT_V];
+                for (int i = 0; i < RMT_V; ++i) upp[i] = up[i];
+                const real d = real(RMT_FP32 ? 3e-4 : 1.5e-8) * rmt_max(rmt_abs(up[c]), real(1e-3));
+                upp[c] += d;
+                rmt_node_post(m, nd, ys, upp, P, kpu, nof);
+                lan[(size_t)z * RMT_V + c] = (double)lco[c];
+                lfd[(size_t)z * RMT_V + c] = (double)(kpu[c] - k[c]) / (double)(upp[c] - up[c]);
+            }
+        }
+#endif
         for (int rr = 0; rr < RMT_V; ++rr)
             for (int c = 0; c < RMT_V; ++c) jan[((size_t)z * RMT_V + rr) * RMT_V + c] = (double)a[rr][c];
         for (int c = 0; c < RMT_V; ++c) {

@@ -242,7 +242,7 @@ class Mechanism:
         if "RMT_KINETICS_SOURCE" not in template:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
         kin = self.device_dag().emit("rmt_kinetics", const_table=bool((defines or {}).get("RMT_KINETICS_KTAB")))
-        if (defines or {}).get("RMT_WITH_ROS4") and self.model != "M2":
+        if (defines or {}).get("RMT_WITH_ROS4"):
             # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i
             kin += self.device_dag().gradient().emit_jac("rmt_kinetics_jac")
         body = template.replace("RMT_KINETICS_SOURCE", kin, 1)

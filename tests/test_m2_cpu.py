@@ -100,6 +100,34 @@ def test_emulated_m2_rk4_vs_reference(g9):
     assert rowwise_err(y[0], traj[:, -1], 7) < 1e-12
 
 
+@pytest.mark.parametrize("zNo", [20, 100])
+def test_m2_analytic_node_jacobian_and_coupling_vs_forward_differences(g9, zNo):
+    """Model M2's rmt_node_jac (host build of the generated source): -d f_z/d y_z and the upwind coupling
+    d f_r/d up_r against the forward differences they replace in the stiff stepper, at the reference-generated G9
+    states: equal to FD accuracy (relative to the node's largest entry)."""
+    mi = INP.m2_dme_input()
+    mech = plan.Mechanism(mi)
+    emu = HostEmu(mech.source(hipbind.kernel_template(), False, 64, 1, None, {"RMT_WITH_ROS4": "1"}), tag="m2jac",
+                  openmp=False)
+    _, row = plan.member_constants_m2(mi, mech, zNo)
+    V = mech.V
+    checked = 0
+    for Y in g9["rhs_%d_y" % zNo]:
+        jan, jfd, lan, lfd = emu.node_jac(Y, row, zNo, coupling=True)
+        ok = np.all(Y.reshape(V, zNo)[:mech.S] > 1e-30, axis=0)
+        ok[1:] &= ok[:-1]
+        scale = np.max(np.abs(jfd), axis=(1, 2), keepdims=True)
+        assert np.max((np.abs(jan - jfd)/scale)[ok]) < 2e-5
+        # coupling: one convective coefficient for all species, one for T; the forward difference is only
+        # well conditioned for the abundant species (a trace species moves its balance by ~1e-11) and for T
+        big = np.argmax(Y.reshape(V, zNo)[:mech.S, 0])
+        for col in (big, V - 1):
+            assert np.max(np.abs(lan[ok, col] - lfd[ok, col])/np.abs(lfd[ok, col])) < 2e-5
+        assert np.all(lan[ok] > 0) and np.all(lan[:, :mech.S] == lan[:, :1])
+        checked += int(ok.sum())
+    assert checked >= zNo
+
+
 def test_m2_kernels_cross_compile_for_gfx950():
     mech = plan.Mechanism(INP.m2_dme_input())
     tpl = hipbind.kernel_template()

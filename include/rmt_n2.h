@@ -149,8 +149,8 @@ int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout
 /* copies the E flag words to host memory (synchronises the stream) and clears them on device */
 int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
 /* which stepper rmt_n2_rk4 / rk45 / ros4 use: 0 = auto (on-chip if N fits one workgroup, else chained
- * workgroups - rk4: any model; rk45: model N2 code objects that hold the on-chip stepper, at most
- * RMT_N2_MAX_CHUNKS chunks of block*nodes_per_thread nodes - else memory; ros4: one workgroup per reactor
+ * workgroups - rk45: code objects that hold the on-chip stepper, at most RMT_N2_MAX_CHUNKS chunks of
+ * block*nodes_per_thread nodes - else memory; ros4: one workgroup per reactor
  * unless the ensemble leaves more than half of the CUs idle, then the reactor is chained over several),
  * 1 = on-chip single workgroup, 2 = one workgroup per reactor with the state in memory, 3 = chained workgroups */
 int rmt_n2_set_mode(rmt_n2_handle* h, int mode);

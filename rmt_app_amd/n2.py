@@ -70,8 +70,8 @@ def rk45_geometry(V, N, fp32=False, chain=True):
     long-lived vectors per node, RMT_RK45_LDS of them in LDS (V*block*npt reals each, at most 136 KiB
     together), the rest in VGPRs - measured on MI355X (profiles/round2_rk45.md): 512 x 2 with 2 vectors in LDS
     for V <= 8, 256 x 2 for the 12-species mechanism.  A reactor that fits one such workgroup runs
-    rmt_n2_rk45_reg; a longer one is cut into chunks of that size on as many CUs (rmt_n2_rk45_chain, model N2:
-    `chain`), up to MAX_CHUNKS; beyond that - and for model M2 - the memory-resident kernel (rk45_block)."""
+    rmt_n2_rk45_reg; a longer one is cut into chunks of that size on as many CUs (rmt_n2_rk45_chain; `chain`),
+    up to MAX_CHUNKS; beyond that the memory-resident kernel (rk45_block)."""
     size = 4 if fp32 else 8
     if V <= 8 and N <= 1024:
         block, npt = choose_geometry(N, V, fp32)
@@ -526,7 +526,7 @@ def open_auto(mech, inputs, zNo, pack, init, sync, fp32, defines, block=None, np
     """The two devices of ivp "hip-auto" (explicit pair in its on-chip geometry, Rosenbrock family) behind one
     AutoStepper; an explicit `block` / `nodes-per-thread` of the solver-config applies to the explicit device."""
     if block is None:
-        b45, n45, d45 = rk45_geometry(mech.V, zNo, fp32, chain=getattr(mech, "model", "N2") != "M2")
+        b45, n45, d45 = rk45_geometry(mech.V, zNo, fp32)
     else:
         b45, n45, d45 = block, npt, {}
     dev45, named_local, IV = open_members(mech, inputs, zNo, pack, init, sync, fp32=fp32, block=b45, npt=n45,

@@ -154,11 +154,13 @@ def test_m2_rk4_end_to_end_vs_scipy_on_oracle_rhs():
     assert np.max(np.abs(got - ref)/np.maximum(np.abs(ref), 1e-6)) < 1e-7
 
 
-@pytest.mark.parametrize("N,E,block,npt", [(1000, 1, 128, 1), (4096, 3, 512, 2), (4100, 2, 256, 1)])
-def test_m2_chained_workgroups_match_memory_stepper(N, E, block, npt):
+@pytest.mark.parametrize("N,E,block,npt,tagged", [(1000, 1, 128, 1, 1), (4096, 3, 512, 2, 1), (4100, 2, 256, 1, 1),
+                                                  (1000, 1, 128, 1, 0), (4096, 3, 512, 2, 0)])
+def test_m2_chained_workgroups_match_memory_stepper(N, E, block, npt, tagged):
     """model M2 spread over several workgroups (upstream record awaited before the Newton sweeps):
-    same result as the memory-resident stepper and as the oracle's RK4"""
-    mi, mech, nm, dev = make_device(N, E=E, block=block, npt=npt)
+    same result as the memory-resident stepper and as the oracle's RK4 - over the tagged-word links (default)
+    and over the flag protocol they replaced (RMT_CHAIN_TAGGED 0)"""
+    mi, mech, nm, dev = make_device(N, E=E, block=block, npt=npt, defines={"RMT_CHAIN_TAGGED": str(tagged)})
     IV = np.tile(plan.initial_state_m2(nm, mech, N), (E, 1))
     dev.set_mode("chain")
     y = dev.to_device(IV)
@@ -175,3 +177,61 @@ def test_m2_chained_workgroups_match_memory_stepper(N, E, block, npt):
         want = O.rk4(0.0, 40*2e-6, 40, pr["IV"], M2O.make_rhs_vec(pr), keep=False)
         assert rowwise_err(a[0], want, mech.V) < 1e-11
     dev.close()
+
+
+def _m2_members(N, E):
+    mi = INP.m2_dme_input()
+    mech = plan.Mechanism(mi)
+    rows, ivs = [], []
+    for e in range(E):
+        m = INP.m2_dme_input()
+        m["operating-conditions"]["temperature"] = mi["operating-conditions"]["temperature"] + 3*(e % 5)
+        nm, row = plan.member_constants_m2(m, mech, N)
+        rows.append(row), ivs.append(plan.initial_state_m2(nm, mech, N))
+    return mech, np.array(rows), np.array(ivs)
+
+
+@pytest.mark.parametrize("N,E", [(2500, 4), (2048, 150)])
+def test_m2_chained_rk45_matches_memory_resident_kernel(N, E):
+    """Model M2 under rmt_n2_rk45_chain (tagged-word links; the upstream chunk's record is awaited BEFORE the
+    pressure sweeps, sent right after them): same step sequences as rmt_n2_rk45_mem, end states equal to rounding
+    at a tolerance that keeps the explicit pair inside its stability region (at rtol 1e-6 the stability-limited
+    steps amplify rounding differences to ~1e-7, tools/microbench/exp_m2_chain.py)."""
+    from rmt_app_amd.n2 import rk45_geometry
+    mech, rows, IV = _m2_members(N, E)
+    block, npt, defs = rk45_geometry(mech.V, N)
+    assert block*npt < N
+    out, stats = {}, {}
+    for mode in ("mem", "chain"):
+        dev = N2Device(mech, rows, N, block=block, npt=npt, defines=defs)
+        dev.set_mode(mode)
+        y = dev.to_device(IV)
+        dev.rk45(y, 0.0, 4e-4, 1e-9, 1e-12, 1e-6, 10**7)
+        dev.rk45(y, 4e-4, 1e-3, 1e-9, 1e-12, -1e-6, 10**7)
+        assert not dev.status().any(), mode
+        out[mode], stats[mode] = y.cpu().numpy(), dev.rk45_stats()
+        dev.close()
+    assert np.array_equal(stats["chain"]["accepted"], stats["mem"]["accepted"])
+    assert np.array_equal(stats["chain"]["rejected"], stats["mem"]["rejected"])
+    for e in range(E):
+        assert rowwise_err(out["chain"][e], out["mem"][e], mech.V) < 1e-11
+
+
+@pytest.mark.parametrize("N,E", [(2000, 1), (1500, 9)])
+def test_m2_chained_stiff_stepper_matches_one_workgroup(N, E):
+    """Model M2 under rmt_n2_ros4_chain: the controller's step history of the one-workgroup kernel and its state to
+    the accuracy of the linear solves."""
+    from rmt_app_amd.settings import DEVICE_DEFAULTS as D
+    mech, rows, IV = _m2_members(N, E)
+    out, stats = {}, {}
+    for mode in ("mem", "chain"):
+        dev = N2Device(mech, rows, N, block=256, npt=1, features=("ros4",))
+        dev.set_mode(mode)
+        y = dev.to_device(IV)
+        dev.ros4(y, 0.0, 1.0, D["ros4-rtol"], D["ros4-atol"], D["ros4-h0"], 10**7)
+        assert not dev.status().any(), mode
+        out[mode], stats[mode] = y.cpu().numpy(), dev.rk45_stats()
+        dev.close()
+    assert np.array_equal(stats["chain"]["accepted"], stats["mem"]["accepted"])
+    for e in range(E):
+        assert rowwise_err(out["chain"][e], out["mem"][e], mech.V) < 1e-8

@@ -440,7 +440,7 @@ def test_rk45_geometry_and_lds_budget():
     assert rk45_geometry(7, 4096) == (512, 2, {"RMT_RK45_LDS": "2"})
     assert rk45_geometry(13, 1024) == (256, 2, {"RMT_RK45_LDS": "2"})
     assert rk45_geometry(7, 16384) == (512, 2, {"RMT_RK45_LDS": "2"})
-    # ... unless that takes more chunks than a team may have, or the model has no chained stepper (M2)
+    # ... unless that takes more chunks than a team may have, or the caller asks for the memory-resident kernel
     assert rk45_geometry(7, 1024*65) == (rk45_block(7, 1024*65), 1, {})
     assert rk45_geometry(7, 4096, chain=False) == (rk45_block(7, 4096), 1, {})
     assert rk45_geometry(13, 1024, chain=False) == (rk45_block(13, 1024), 1, {})

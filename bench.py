@@ -198,9 +198,9 @@ def single_reactor_4096(mech, inputs):
 def adaptive_rk45(mech, rows, IV, n_nodes):
     """BASELINE configs[4]: adaptive Dormand-Prince RK45 with per-reactor step control on the device
     (rmt_n2_rk45_reg, on chip) - accepted node-steps/s of this rank's sweep over 8 ms of reactor time after
-    a warm-up interval, and the 12-species / 8-reaction mechanism on 64 x 512 nodes (one workgroup per
-    reactor) and on this rank's share of configs[4], 256 x 1024 nodes (rmt_n2_rk45_chain: two chunks per
-    reactor)."""
+    a warm-up interval, and the 12-species / 8-reaction mechanism on 64 x 512 nodes (rmt_n2_rk45_chain: the
+    ensemble alone would leave 3/4 of the CUs idle, so every reactor is cut into 4 chunks) and on this rank's
+    share of configs[4], 256 x 1024 nodes (two chunks per reactor)."""
     import inputs as INP
     from rmt_app_amd import plan
     from rmt_app_amd.n2 import N2Device, rk45_geometry
@@ -213,7 +213,7 @@ def adaptive_rk45(mech, rows, IV, n_nodes):
             mech_ = plan.Mechanism(mi)
             nm, row = plan.member_constants(mi, mech_, N)
             rows_, IV_ = np.tile(row, (rows_, 1)), np.tile(plan.initial_state(nm, mech_, N), (rows_, 1))
-        block, npt, defs = rk45_geometry(mech_.V, N)
+        block, npt, defs = rk45_geometry(mech_.V, N, E=len(rows_))      # (what rmtExe picks for this ensemble)
         dev = N2Device(mech_, rows_, N, block=block, npt=npt, defines=defs)
         y = dev.to_device(IV_)
         dev.rk45(y, 0.0, 1e-5, 1e-6, 1e-9, 1e-6, 10**8)
@@ -279,14 +279,14 @@ def prebuild(members=MEMBERS_PER_GPU, n_nodes=N_NODES):
     keys.append(precompile(mech, r4096, 4096))
     keys.append(precompile(mech, r4096, 4096, block=256, npt=1, features=("ros4",)))
     # adaptive_rk45: the sweep and the 12-species mechanism
-    block, npt, defs = rk45_geometry(mech.V, n_nodes)
+    block, npt, defs = rk45_geometry(mech.V, n_nodes, E=members)
     keys.append(precompile(mech, rows, n_nodes, block=block, npt=npt, defines=defs))
     ms = plan.Mechanism(INP.syn12_input())
     _, rs = plan.member_constants(INP.syn12_input(), ms, 512)
-    block, npt, defs = rk45_geometry(ms.V, 512)
+    block, npt, defs = rk45_geometry(ms.V, 512, E=64)
     keys.append(precompile(ms, np.tile(rs, (64, 1)), 512, block=block, npt=npt, defines=defs))
     _, rs = plan.member_constants(INP.syn12_input(), ms, 1024)
-    block, npt, defs = rk45_geometry(ms.V, 1024)
+    block, npt, defs = rk45_geometry(ms.V, 1024, E=256)
     keys.append(precompile(ms, np.tile(rs, (256, 1)), 1024, block=block, npt=npt, defines=defs))
     # time_to_solution
     keys.append(precompile(mech, rows, n_nodes, block=256, npt=1, features=("ros4",)))

@@ -61,7 +61,7 @@ def run_m2(modelInput, members_inputs=None):
         block, npt = ros4_block(mech.V, zNo), 1
     defines = {}
     if ivp == "hip-rk45" and block is None:
-        block, npt, defines = rk45_geometry(mech.V, zNo)
+        block, npt, defines = rk45_geometry(mech.V, zNo, E=len(inputs) if sync is None else max(sync.counts))
     if ivp == "hip-auto":               # the reference's LSODA: automatic stiff / non-stiff choice (n2.AutoStepper)
         dev, named_local, IV = open_auto(mech, inputs, zNo, plan.member_constants_m2, plan.initial_state_m2, sync,
                                          False, None, block, npt)

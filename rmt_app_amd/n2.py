@@ -65,22 +65,33 @@ def rk45_block(V, N, fp32=False):
 MAX_CHUNKS = 64          # include/rmt_n2.h RMT_N2_MAX_CHUNKS
 
 
-def rk45_geometry(V, N, fp32=False, chain=True):
+def rk45_geometry(V, N, fp32=False, chain=True, E=None):
     """(block, nodes_per_thread, defines) for the adaptive explicit stepper.  The on-chip kernels keep 4
     long-lived vectors per node, RMT_RK45_LDS of them in LDS (V*block*npt reals each, at most 136 KiB
     together), the rest in VGPRs - measured on MI355X (profiles/round2_rk45.md): 512 x 2 with 2 vectors in LDS
     for V <= 8, 256 x 2 for the 12-species mechanism.  A reactor that fits one such workgroup runs
     rmt_n2_rk45_reg; a longer one is cut into chunks of that size on as many CUs (rmt_n2_rk45_chain; `chain`),
-    up to MAX_CHUNKS; beyond that the memory-resident kernel (rk45_block)."""
+    up to MAX_CHUNKS; beyond that the memory-resident kernel (rk45_block).
+    `E` (reactors on this GPU, when the caller knows it): an ensemble that leaves CUs idle with those chunks is cut
+    finer - ONE node per lane, chunks of 512 / 256 nodes (256 / 128 for V > 8) - as long as all chunks of all
+    reactors stay co-resident: a step is latency-bound per lane, so half the work per lane on twice the CUs is
+    30-70 % faster (profiles/round2_rk45_chain.md)."""
     size = 4 if fp32 else 8
-    if V <= 8 and N <= 1024:
+    big = V <= 8
+    if big and N <= 1024:
         block, npt = choose_geometry(N, V, fp32)
     elif N <= 512:
         block, npt = (256, 2) if N > 256 else (64*((N + 63)//64), 1)
-    elif chain and -(-N//(1024 if V <= 8 else 512)) <= min(MAX_CHUNKS, N_CUS):
-        block, npt = (512, 2) if V <= 8 else (256, 2)
+    elif chain and -(-N//(1024 if big else 512)) <= min(MAX_CHUNKS, N_CUS):
+        block, npt = (512, 2) if big else (256, 2)
     else:
         return rk45_block(V, N, fp32), 1, {}
+    if chain and E is not None and N > 256:
+        for blk in ((256, 512) if big else (128, 256)):          # finest first
+            C = -(-N//blk)
+            if C >= 2 and blk < block*npt and E*C <= N_CUS and C <= MAX_CHUNKS:
+                block, npt = blk, 1
+                break
     slots = 2
     while slots > 0 and slots*V*block*npt*size > 136*1024:
         slots -= 1
@@ -526,7 +537,7 @@ def open_auto(mech, inputs, zNo, pack, init, sync, fp32, defines, block=None, np
     """The two devices of ivp "hip-auto" (explicit pair in its on-chip geometry, Rosenbrock family) behind one
     AutoStepper; an explicit `block` / `nodes-per-thread` of the solver-config applies to the explicit device."""
     if block is None:
-        b45, n45, d45 = rk45_geometry(mech.V, zNo, fp32)
+        b45, n45, d45 = rk45_geometry(mech.V, zNo, fp32, E=len(inputs) if sync is None else max(sync.counts))
     else:
         b45, n45, d45 = block, npt, {}
     dev45, named_local, IV = open_members(mech, inputs, zNo, pack, init, sync, fp32=fp32, block=b45, npt=n45,
@@ -662,7 +673,7 @@ def run_n2(modelInput, members_inputs=None):
     # "strict-flags": test the Python-exception conditions on every RK stage (default: stage 1 only)
     defines = {"RMT_CHECK_ALL_STAGES": "1"} if cfg.get('strict-flags') else {}
     if ivp == "hip-rk45" and block is None:
-        block, npt, geo_defs = rk45_geometry(mech.V, zNo, fp32)
+        block, npt, geo_defs = rk45_geometry(mech.V, zNo, fp32, E=len(inputs) if sync is None else max(sync.counts))
         defines.update(geo_defs)
     if ivp == "hip-auto":
         dev, named_local, IV = open_auto(mech, inputs, zNo, plan.member_constants, plan.initial_state, sync, fp32,

@@ -154,3 +154,24 @@ def test_rmtexe_rk45_on_a_mesh_beyond_one_workgroup():
         assert a.shape == b.shape == (7, 1100)
         worst = max(worst, float(np.max(np.abs(a - b)/np.maximum(np.abs(b), 1e-300))))
     assert worst < 1e-6, worst
+
+
+@pytest.mark.parametrize("name,N,E", [("dme_nb", 1024, 40), ("syn12", 512, 30), ("dme_nb", 1000, 1)])
+def test_small_ensembles_are_cut_finer_and_agree_with_one_workgroup_per_reactor(name, N, E):
+    """rk45_geometry with a known ensemble size: an ensemble that leaves CUs idle is cut into finer chunks (one
+    node per lane); same step sequences and the same end states (rounding) as one workgroup per reactor."""
+    mech, rows, IV, _ = _members(name, N, [523 + (e % 9) if name == "dme_nb" else 600 + 3*(e % 9) for e in range(E)])
+    coarse = rk45_geometry(mech.V, N)
+    fine = rk45_geometry(mech.V, N, E=E)
+    assert coarse[0]*coarse[1] >= N and fine[0]*fine[1] < N and fine[1] == 1
+    out, stats = {}, {}
+    for tag, (block, npt, defs) in (("coarse", coarse), ("fine", fine)):
+        dev = N2Device(mech, rows, N, block=block, npt=npt, defines=defs)
+        y = dev.to_device(IV)
+        dev.rk45(y, 0.0, 2e-3 if name == "dme_nb" else 3e-2, 1e-6, 1e-9, 1e-6, 10**7)     # auto mode
+        assert not dev.status().any(), tag
+        out[tag], stats[tag] = y.cpu().numpy(), dev.rk45_stats()
+        dev.close()
+    assert np.array_equal(stats["fine"]["accepted"], stats["coarse"]["accepted"])
+    assert np.array_equal(stats["fine"]["rejected"], stats["coarse"]["rejected"])
+    assert _rel(out["fine"], out["coarse"], E, mech.V, N) < 1e-11

@@ -450,6 +450,22 @@ def test_rk45_geometry_and_lds_budget():
     for V, N in ((7, 4096), (13, 1024), (7, 16384)):
         block, npt, defs = rk45_geometry(V, N)
         assert int(defs["RMT_RK45_LDS"])*V*block*npt*8 <= 136*1024
+    # a known ensemble size that leaves CUs idle: one node per lane, finer chunks, all of them co-resident
+    assert rk45_geometry(7, 1024, E=256)[:2] == (512, 2)          # the device is full: one workgroup per reactor
+    assert rk45_geometry(7, 1024, E=128)[:2] == (512, 1)          # 2 chunks x 128 reactors
+    assert rk45_geometry(7, 1024, E=64)[:2] == (256, 1)           # 4 chunks x 64
+    assert rk45_geometry(7, 1024, E=1)[:2] == (256, 1)
+    assert rk45_geometry(7, 4096, E=32)[:2] == (512, 1)           # 8 chunks x 32
+    assert rk45_geometry(7, 4096, E=8)[:2] == (256, 1)
+    assert rk45_geometry(7, 4096, E=64)[:2] == (512, 2)           # 4 chunks x 64 fill the device already
+    assert rk45_geometry(7, 16384, E=1)[:2] == (256, 1)           # 64 chunks = RMT_N2_MAX_CHUNKS
+    assert rk45_geometry(13, 1024, E=64)[:2] == (256, 1)
+    assert rk45_geometry(13, 512, E=64)[:2] == (128, 1)
+    assert rk45_geometry(13, 1024, E=256)[:2] == (256, 2)
+    assert rk45_geometry(7, 200, E=1)[:2] == rk45_geometry(7, 200)[:2]
+    for V, N, E in ((7, 1024, 64), (13, 1024, 64), (7, 16384, 1), (7, 4096, 8)):
+        block, npt, defs = rk45_geometry(V, N, E=E)
+        assert E*(-(-N//(block*npt))) <= 256 and -(-N//(block*npt)) <= 64
 
 
 def test_device_stats_totals():

@@ -40,7 +40,7 @@ def run_rk45(name, N, E, t1, rtol):
     mi = INP.ALL_N2_INPUTS[name]()
     mech = plan.Mechanism(mi)
     nm, row = plan.member_constants(mi, mech, N)
-    block, npt, defs = rk45_geometry(mech.V, N)                                           # what rmtExe(ivp="hip-rk45") picks
+    block, npt, defs = rk45_geometry(mech.V, N, E=E)                                      # what rmtExe(ivp="hip-rk45") picks
     dev = N2Device(mech, np.tile(row, (E, 1)), N, block=block, npt=npt, defines=defs)
     y = dev.to_device(np.tile(plan.initial_state(nm, mech, N), (E, 1)))
     dev.rk45(y, 0.0, 1e-5, rtol, 1e-3*rtol, 1e-6, 10**8)         # warm-up launch

@@ -175,3 +175,18 @@ def test_small_ensembles_are_cut_finer_and_agree_with_one_workgroup_per_reactor(
     assert np.array_equal(stats["fine"]["accepted"], stats["coarse"]["accepted"])
     assert np.array_equal(stats["fine"]["rejected"], stats["coarse"]["rejected"])
     assert _rel(out["fine"], out["coarse"], E, mech.V, N) < 1e-11
+
+
+def test_forced_chain_mode_on_a_reactor_that_fits_one_workgroup_is_refused():
+    """mode 3 (chained) needs at least two chunks: the library refuses with a message instead of launching."""
+    from rmt_app_amd.hipbind import RmtN2Error
+    mech, rows, IV, _ = _members("dme_nb", 200, (523,))
+    dev = N2Device(mech, rows, 200, block=256, npt=1, defines={"RMT_RK45_LDS": "2"})
+    dev.set_mode("chain")
+    y = dev.to_device(IV)
+    with pytest.raises(RmtN2Error, match="chained rk45 needs"):
+        dev.rk45(y, 0.0, 1e-4, 1e-6, 1e-9, 1e-6, 10**6)
+    dev.set_mode("auto")
+    dev.rk45(y, 0.0, 1e-4, 1e-6, 1e-9, 1e-6, 10**6)          # the handle is still usable
+    assert not dev.status().any()
+    dev.close()

@@ -50,7 +50,8 @@ def run_rk45(name, N, E, t1, rtol):
     fl = dev.status()
     acc, rej = int(st["accepted"].sum()), int(st["rejected"].sum())
     print("| %s | %d | %d | rk45_%s %dx%d | acc %d rej %d (t1=%g, rtol=%g) | %.3f | %.3e | %s |" % (
-        name, N, E, "reg" if defs else "mem", dev.block, dev.npt, acc, rej, t1, rtol, ms, N*acc/(ms/1e3), "ok" if not fl.any() else hex(int(fl.max()))),
+        name, N, E, ("reg" if N <= dev.block*dev.npt else "chain[%d]" % (-(-N//(dev.block*dev.npt)))) if defs else "mem",
+        dev.block, dev.npt, acc, rej, t1, rtol, ms, N*acc/(ms/1e3), "ok" if not fl.any() else hex(int(fl.max()))),
         flush=True)
     dev.close()
 

@@ -449,20 +449,31 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
         // latency, ~0.3 stage-block times); chunks of b > 1 blocks run all six stages of a block before the
         // next one (the block's stage vectors live in LDS), so a downstream chunk starts 6(b-1) stage-block
         // times late.  Estimated step time in stage-block units, minimised over the chunk count:
-        const int per_member = h->n_cus / (h->E < h->n_cus ? h->E : h->n_cus);     // CUs one reactor can have
-        int cmax = nblocks < per_member ? nblocks : per_member;
+        // The T = #CUs / C teams of a launch work through the reactors in rounds of T, so the job costs
+        // ceil(E / T) rounds of that step time - against ceil(E / #CUs) rounds of 6 nblocks for one workgroup per
+        // reactor.  (Few chunks of several blocks lose to many one-block chunks run in more rounds: 8 reactors of
+        // 16384 nodes take 2.99 s as 32 chunks x 8 teams and 0.36 s as 64 chunks x 4 teams x 2 rounds.)
+        int cmax = nblocks < h->n_cus ? nblocks : h->n_cus;
         if (cmax > RMT_N2_MAX_CHUNKS) cmax = RMT_N2_MAX_CHUNKS;
-        double best = 6.0 * nblocks;
+        double best = 6.0 * nblocks * ((h->E + h->n_cus - 1) / h->n_cus);
         for (int c = 2; c <= cmax; ++c) {
             const int b = (nblocks + c - 1) / c;
             const int cc = (nblocks + b - 1) / b;
-            const double cost = 6.0 * b + (cc - 1) * (6.0 * (b - 1) + 0.3);
+            int teams = h->n_cus / cc;
+            if (teams > h->E) teams = h->E;
+            const int rounds = (h->E + teams - 1) / teams;
+            // (x 1.35: a chained stage-block is slower than a resident one - its sweeps exchange the chunk
+            // boundary over the links; calibrated on the 4096-node reactor, 97 us per step in 16 chunks)
+            const double cost = 1.35 * rounds * (6.0 * b + (cc - 1) * (6.0 * (b - 1) + 0.3));
             if (cost < best || (h->mode == 3 && C < 2)) { best = cost; C = cc; }
         }
-        if (h->mode == 0 && 2 * h->E > h->n_cus) C = 1;       // the ensemble fills the device by itself
+        if (const char* force = getenv("RMT_N2_ROS4_CHUNKS")) {       // tuning experiments: chunk count by hand
+            const int c = atoi(force);
+            if (c >= 1 && c <= cmax) C = c;
+        }
     }
     if (h->mode == 3 && C < 2)
-        return fail("chained stiff stepper needs >= 2 node blocks per reactor and E < #CUs (N=%d block=%d E=%d CUs=%d)",
+        return fail("chained stiff stepper needs >= 2 node blocks per reactor (N=%d block=%d E=%d CUs=%d)",
                     h->N, h->block, h->E, h->n_cus);
     if (C >= 2) {
         const int bpc = (nblocks + C - 1) / C;          // node blocks per chunk

@@ -150,8 +150,8 @@ int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout
 int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
 /* which stepper rmt_n2_rk4 / rk45 / ros4 use: 0 = auto (on-chip if N fits one workgroup, else chained
  * workgroups - rk45: code objects that hold the on-chip stepper, at most RMT_N2_MAX_CHUNKS chunks of
- * block*nodes_per_thread nodes - else memory; ros4: one workgroup per reactor
- * unless the ensemble leaves more than half of the CUs idle, then the reactor is chained over several),
+ * block*nodes_per_thread nodes - else memory; ros4: one workgroup per reactor unless cutting the reactors
+ * into chunks on several CUs, the teams working through the ensemble in rounds, is estimated to be faster),
  * 1 = on-chip single workgroup, 2 = one workgroup per reactor with the state in memory, 3 = chained workgroups */
 int rmt_n2_set_mode(rmt_n2_handle* h, int mode);
 /* timing of the last rk4/rk45/rhs launch in ms (HIP events on the handle's stream; synchronises) */

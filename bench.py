@@ -427,7 +427,13 @@ def main():
                           "of %s: %d v_*_f64 of %d VALU, %d scratch, %d lane moves" % (
                               ist["digest"], kname, loop["valu_f64"], loop["valu"], loop["scratch"], loop["lane_moves"]),
                           "achieved_Tops": valu_rate/1e12, "peak_Tops": FP64_PEAK_TOPS,
-                          "frac": valu_rate/(FP64_PEAK_TOPS*1e12)},
+                          "frac": valu_rate/(FP64_PEAK_TOPS*1e12),
+                          # what this instruction mix could reach with no stall at all, from the measured issue costs
+                          # of profiles/round2_issue_model.md (2 waves/SIMD: 4.8 cycles per fp64 VALU instruction,
+                          # ~3 per other VALU instruction, against the 4 cycles `peak_Tops` assumes)
+                          "mix_ceiling_frac": 4.0*loop["valu_f64"]/(4.8*loop["valu_f64"]
+                                                                    + 3.0*(loop["valu"] - loop["valu_f64"])),
+                          "mix_ceiling_source": "profiles/round2_issue_model.md (tools/microbench/issue.hip)"},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(mech, rows, IV, n_nodes)

@@ -70,6 +70,20 @@ class HostEmu:
         self.lib.emu_n1_rhs(u.ctypes.data, out.ctypes.data, members1.ctypes.data, E, flags.ctypes.data)
         return out, flags
 
+    def n1_jac(self, u, members1):
+        """Model N1 (source generated with defines={"RMT_WITH_N1": "1"}): analytic and forward-difference -d du/d u,
+        each [E][V1][V1], and the right-hand sides of rmt_n1_rhs_jac / rmt_n1_rhs, each [E][V1]."""
+        u = np.ascontiguousarray(u, dtype=self.dtype)
+        E, V1 = u.shape
+        members1 = np.ascontiguousarray(members1, dtype=np.float64).reshape(E, -1)
+        jan, jfd = np.zeros((E, V1, V1)), np.zeros((E, V1, V1))
+        fan, fref = np.zeros((E, V1)), np.zeros((E, V1))
+        self.lib.emu_n1_jac.argtypes = [C.c_void_p]*2 + [C.c_int] + [C.c_void_p]*4
+        self.lib.emu_n1_jac.restype = None
+        self.lib.emu_n1_jac(u.ctypes.data, members1.ctypes.data, E, jan.ctypes.data, jfd.ctypes.data,
+                            fan.ctypes.data, fref.ctypes.data)
+        return jan, jfd, fan, fref
+
     def node_jac(self, y, member, N, coupling=False):
         """(analytic, forward-difference) node Jacobians -d f_z/d y_z, each [N][V][V], of one reactor state
         (needs a source generated with defines={"RMT_WITH_ROS4": "1"}); coupling=True (model M2): also the

@@ -78,6 +78,36 @@ extern "C" void emu_n1_rhs(const real* u, real* du, const double* members1, int 
     }
 }
 
+#if RMT_WITH_N1
+// Model N1: analytic -d du/d u (rmt_n1_rhs_jac) next to the forward differences of rmt_n1_rhs it replaces, and the
+// right-hand side both functions return; jan / jfd are [E][V1][V1], fan / fref [E][V1].
+extern "C" void emu_n1_jac(const real* u, const double* members1, int E, double* jan, double* jfd, double* fan,
+                           double* fref) {
+    rmt_noflags_t nof;
+    for (int e = 0; e < E; ++e) {
+        real uu[RMT_V1], f0[RMT_V1], fa[RMT_V1], a[RMT_V1][RMT_V1];
+        for (int i = 0; i < RMT_V1; ++i) uu[i] = u[(size_t)e * RMT_V1 + i];
+        const double* mr = members1 + (size_t)e * RMT_NM1;
+        rmt_n1_rhs(mr, uu, f0, nof);
+        rmt_n1_rhs_jac(mr, uu, fa, a, nof);
+        for (int r = 0; r < RMT_V1; ++r) {
+            fan[(size_t)e * RMT_V1 + r] = (double)fa[r];
+            fref[(size_t)e * RMT_V1 + r] = (double)f0[r];
+            for (int c = 0; c < RMT_V1; ++c) jan[((size_t)e * RMT_V1 + r) * RMT_V1 + c] = (double)a[r][c];
+        }
+        for (int c = 0; c < RMT_V1; ++c) {
+            real up[RMT_V1], fp[RMT_V1];
+            for (int i = 0; i < RMT_V1; ++i) up[i] = uu[i];
+            const real d = real(RMT_FP32 ? 3e-4 : 1.5e-8) * rmt_max(rmt_abs(uu[c]), real(1e-3));
+            up[c] += d;
+            rmt_n1_rhs(mr, up, fp, nof);
+            for (int r = 0; r < RMT_V1; ++r)
+                jfd[((size_t)e * RMT_V1 + r) * RMT_V1 + c] = -(double)(fp[r] - f0[r]) / (double)(up[c] - uu[c]);
+        }
+    }
+}
+#endif
+
 extern "C" void emu_rk4(real* y, const double* members, int N, int E, double h_, long long nsteps,
                         unsigned* flags) {
     const real h = real(h_), hh = real(0.5 * h_), h6 = real(h_ / 6.0);

@@ -898,14 +898,17 @@ class Gradient(Lowered):
             pos += len(p)
         return vals[:R], out
 
-    def emit_jac(self, fname="rmt_kinetics_jac"):
+    def emit_jac(self, fname="rmt_kinetics_jac", with_p=False):
         """Device function: rates r[R] and the partials drdT[R], drdx[R][S], drdC[R][S] (zeros written
-        as literals, which the compiler then removes from the chain rule of the node Jacobian)."""
+        as literals, which the compiler then removes from the chain rule of the node Jacobian); with_p: also
+        drdP[R] (model N1, where the pressure is a state variable - the gradient must have been taken by "P" too)."""
         lines, name = self._emit_body(nocheck_from=self.n_primal)
         S, R = self.S, self.n_rates
         outs = ["    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.rate_outputs)]
         for q, p in enumerate(self.partial):
             outs.append("    drdT[%d] = %s;" % (q, name[p["T"]] if "T" in p else "real(0)"))
+            if with_p:
+                outs.append("    drdP[%d] = %s;" % (q, name[p["P"]] if "P" in p else "real(0)"))
             for i in range(S):
                 outs.append("    drdx[%d][%d] = %s;" % (q, i, name[p["x%d" % i]] if ("x%d" % i) in p else "real(0)"))
                 outs.append("    drdC[%d][%d] = %s;" % (q, i, name[p["C%d" % i]] if ("C%d" % i) in p else "real(0)"))
@@ -913,9 +916,9 @@ class Gradient(Lowered):
             "template <typename FL>\n"
             "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
             "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r,\n"
-            "        real* __restrict__ drdT, real (*__restrict__ drdx)[RMT_S], real (*__restrict__ drdC)[RMT_S], FL& flag) {\n"
+            "        real* __restrict__ drdT, real (*__restrict__ drdx)[RMT_S], real (*__restrict__ drdC)[RMT_S],%s FL& flag) {\n"
             "    (void)invT;\n%s\n%s\n}\n"
-            % (fname, "\n".join(lines), "\n".join(outs)))
+            % (fname, " real* __restrict__ drdP," if with_p else "", "\n".join(lines), "\n".join(outs)))
 
 
 def trace(VARS, RATES, nspecies, R_CONST=8.314472, fixed=None):

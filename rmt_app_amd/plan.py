@@ -245,6 +245,11 @@ class Mechanism:
         if (defines or {}).get("RMT_WITH_ROS4"):
             # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i
             kin += self.device_dag().gradient().emit_jac("rmt_kinetics_jac")
+        if (defines or {}).get("RMT_WITH_N1"):
+            # steady-state model N1: the pressure is a state variable, so the partials by P as well
+            dag = self.device_dag()
+            wrt = sorted({dag.g.nodes[i][1] for i in dag.live if dag.g.nodes[i][0] == "in"})
+            kin += dag.gradient(wrt=wrt).emit_jac("rmt_kinetics_jacp", with_p=True)
         body = template.replace("RMT_KINETICS_SOURCE", kin, 1)
         return self.prelude(fp32, block, npt, lds_state, defines) + body
 

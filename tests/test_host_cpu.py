@@ -345,6 +345,23 @@ def test_generated_n1_node_function_vs_reference(template):
         assert relerr(out[k], F[k]) < (1e-11 if k < 2 else 1e-7), (k, out[k], F[k])
 
 
+def test_n1_analytic_jacobian_vs_forward_differences(template):
+    """Model N1's rmt_n1_rhs_jac (host build of the generated source): its right-hand side equals rmt_n1_rhs and
+    its Jacobian - rates differentiated symbolically by T, P, x_i, C_i, the rest by hand - equals the (S+2)
+    forward differences it replaces to FD accuracy, at the reference-generated G6 states."""
+    g = np.load(os.path.join(G, "g6_n1.npz"))
+    mi = INP.n1_notebook_input()
+    mech = plan.Mechanism(mi)
+    _, row = plan.member_constants_n1(mi, mech)
+    emu = HostEmu(mech.source(template, defines={"RMT_WITH_N1": "1"}), tag="dme_n1jac", openmp=False)
+    Y = g["rhs_y"]
+    jan, jfd, fan, fref = emu.n1_jac(Y, np.tile(row, (len(Y), 1)))
+    assert np.max(np.abs(fan - fref)/np.maximum(np.abs(fref), 1e-300)) < 1e-12
+    for k in range(len(Y)):
+        scale = np.max(np.abs(jfd[k]), axis=1, keepdims=True)          # row-relative: the rows differ by 1e6 in size
+        assert np.max(np.abs(jan[k] - jfd[k])/scale) < 1e-4, (k, np.max(np.abs(jan[k] - jfd[k])/scale))   # (FD noise of the trace species)
+
+
 def test_benchmark_mesh_golden_g8_vs_emulated_rk4(template):
     """Golden G8 (SciPy DOP853, rtol 1e-10, on the oracle's vectorised RHS at zNo = 1024;
     tools/make_mesh_golden.py) cross-checked on the CPU by an independent integration: the host

@@ -52,17 +52,22 @@ def test_chained_stiff_stepper_agrees_with_single_workgroup(N, temps, block):
     dev.close()
 
 
-def test_chained_stiff_stepper_two_chunks_of_two_blocks_70_reactors():
-    """70 reactors x 1024 nodes: the host gives every reactor 256/70 = 3 CUs -> 2 chunks of 2 node blocks,
-    70 teams - the carry between the blocks of a chunk and the link between the chunks in one launch."""
+@pytest.mark.parametrize("chunks", [None, "2"])
+def test_chained_stiff_stepper_70_reactors_rounds_of_teams_and_multi_block_chunks(chunks, monkeypatch):
+    """70 reactors x 1024 nodes.  The host's estimate picks 4 one-block chunks per reactor: 64 teams, so six teams
+    integrate a second reactor after their first (rounds).  RMT_N2_ROS4_CHUNKS=2 forces 2 chunks of 2 node blocks:
+    the carry between the blocks of a chunk and the link between the chunks in one launch."""
     N, E = 1024, 70
     mech, rows, IV, _ = _members(N, tuple(503 + 0.5*e for e in range(E)))
     dev = N2Device(mech, rows, N, block=256, npt=1, features=("ros4",))
     res = {}
     for mode in ("mem", "chain"):
+        if chunks and mode == "chain":
+            monkeypatch.setenv("RMT_N2_ROS4_CHUNKS", chunks)
         dev.set_mode(mode)
         y = dev.to_device(IV)
         dev.ros4(y, 0.0, 5e-3, 1e-6, 1e-9, 1e-5, 10**6)
+        monkeypatch.delenv("RMT_N2_ROS4_CHUNKS", raising=False)
         assert not dev.status().any(), mode
         res[mode] = (y.cpu().numpy().reshape(E, 7, N), dev.rk45_stats()["accepted"].copy())
     np.testing.assert_array_equal(res["chain"][1], res["mem"][1])

@@ -142,6 +142,8 @@ int rmt_n2_rk45(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rt
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 int rmt_n2_ros4(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rtol, double atol,
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
+/* (tuning experiments: the environment variable RMT_N2_ROS4_CHUNKS=c overrides the number of chunks rmt_n2_ros4 cuts a
+ * reactor into, 1 = one workgroup per reactor; unset = the library's estimate) */
 /* members1: HOST [E][16+S] rows (layout M1_* in n2_kernels.inc); out: DEVICE double [E][nout][S+2]
  * (S+1 when iso-thermal) = the state at z* = k/(nout-1); stats: DEVICE [E] */
 int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout, double rtol,

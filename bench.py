@@ -311,13 +311,26 @@ def main():
     ap.add_argument("--define", action="append", default=[], help="kernel tuning macro NAME=VALUE")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    # `python bench.py --gpus N` starts its N ranks itself (one process per GPU under torch.distributed.run,
+    # rendezvous on 127.0.0.1) BEFORE this process touches the GPU, and exits with their status; under the
+    # driver's own torchrun line the ranks arrive here with RANK / WORLD_SIZE set and simply run.
+    from rmt_app_amd import launch
+    if args.gpus > 1 and not launch.is_rank():
+        sys.exit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started as one of %d ranks: launch it with "
+                         "--nproc-per-node %d (or plainly, and it starts the ranks itself)"
+                         % (args.gpus, world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("rank %d (local %d) has no GPU: %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ   # under torchrun, even alone
     if distributed:
@@ -375,6 +388,15 @@ def main():
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
+    # what the driver needs to see that RCCL really had N ranks: the group's size and every rank's own kernel time
+    kms = torch.tensor([kernel_ms], device="cuda", dtype=torch.float64)
+    if distributed:
+        parts = [torch.zeros_like(kms) for _ in range(world)]
+        dist.all_gather(parts, kms)
+        kernel_ms_ranks = [float(p.item()) for p in parts]
+        rccl_ranks, backend = dist.get_world_size(), dist.get_backend()
+    else:
+        kernel_ms_ranks, rccl_ranks, backend = [float(kernel_ms)], 1, None
     outlet = ens.gather_outlet(y)          # [world*E][V] on rank 0: the sweep's result table
     if rank == 0:
         assert outlet.shape == (total, mech.V) and bool(torch.isfinite(outlet).all())
@@ -402,12 +424,16 @@ def main():
             "value": value, "unit": "mesh-node-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3*tmax/args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rccl_ranks": rccl_ranks, "dist_backend": backend, "kernel_ms_per_rank": kernel_ms_ranks,
             "config": {"workload": "DME N2 (TEST2.ipynb reactor), %d nodes, RK4 dt=2e-6 s, %d "
                                    "reactors/GPU of the 64x32 inlet-T/P sweep; one step = one output interval "
                                    "= one launch of %d RK4 steps" % (n_nodes, E, RK4_PER_STEP),
                        "rk4_steps_per_step": RK4_PER_STEP,
                        "members_per_gpu": E, "nodes": n_nodes, "integrator": "rk4",
                        "parallelism": "ensemble-dp%d" % world,
+                       "extras": ("full (cpu_baseline, accuracy, single reactor, mesh sweep, adaptive, time to "
+                                  "solution)" if (world == 1 and not args.no_cpu_baseline) else
+                                  "throughput line only (the extra measurements run at N = 1)"),
                        "kernel": "%s block=%d npt=%d lds_state=%d" % (kname, dev.block, dev.npt, dev.lds_state),
                        "kernel_digest": ist["kernel_digest"], "code_object_digest": ist["digest"]},
             # contract form: ALGORITHMIC bytes (2(S+2)8 B per node-step) / kernel time against the

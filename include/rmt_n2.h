@@ -76,11 +76,11 @@ extern "C" {
  * restores the caller's current device before returning. */
 
 /* chained steppers (rmt_n2_ros4 / rmt_n2_rk45 / rmt_n2_rk4 with one reactor over several CUs): ring depth of a tagged-word link
- * (= RMT_RING of n2_kernels.inc) and the largest number of chunks one reactor is cut into */
+ * (= RMT_RING of csrc/kernels/30_lanes_links.inc) and the largest number of chunks one reactor is cut into */
 #define RMT_N2_RING 512
 #define RMT_N2_MAX_CHUNKS 64
 
-/* member row layout: doubles per reactor = 16 + S (see rmt_app_amd/csrc/n2_kernels.inc M_*) */
+/* member row layout: doubles per reactor = 16 + S (see rmt_app_amd/csrc/kernels/00_config_math.inc M_*) */
 #define RMT_N2_MEMBER_FIXED 16
 
 typedef struct rmt_n2_plan {
@@ -144,7 +144,7 @@ int rmt_n2_ros4(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rt
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 /* (tuning experiments: the environment variable RMT_N2_ROS4_CHUNKS=c overrides the number of chunks rmt_n2_ros4 cuts a
  * reactor into, 1 = one workgroup per reactor; unset = the library's estimate) */
-/* members1: HOST [E][16+S] rows (layout M1_* in n2_kernels.inc); out: DEVICE double [E][nout][S+2]
+/* members1: HOST [E][16+S] rows (layout M1_* in csrc/kernels/22_node_n1.inc); out: DEVICE double [E][nout][S+2]
  * (S+1 when iso-thermal) = the state at z* = k/(nout-1); stats: DEVICE [E] */
 int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout, double rtol,
                    double atol, double h0, int64_t max_steps, rmt_n2_stats* stats_out);

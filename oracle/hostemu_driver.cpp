@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE ONLY (lives under oracle/, never linked into the product library).
 //
-// Compiles the SAME generated source the GPU gets (prelude + n2_kernels.inc with the lowered
+// Compiles the SAME generated source the GPU gets (prelude + the csrc/kernels/*.inc template with the lowered
 // kinetics) for the host with g++, using only its per-node physics (rmt_node_pre/rmt_node_post)
 // and a plain sequential driver: pressure marched node by node exactly like the reference's loop
 // (PyREMOT/docs/pbHomoReactor.py:3892-3979), RK4 as PyREMOT/solvers/odeSolver.py:17-40.

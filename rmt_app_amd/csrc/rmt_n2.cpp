@@ -1,6 +1,6 @@
 // C-ABI host side of the MI355X N2 integrator (see include/rmt_n2.h for the contract and the
 // reference interfaces each entry point replaces).  Host code only: the device code is the
-// template in n2_kernels.inc, specialised by a generated prelude and compiled with hipRTC.
+// template in kernels/*.inc (concatenated by embed.py in the order of kernels/ORDER), specialised by a generated prelude and compiled with hipRTC.
 #include "rmt_n2.h"
 
 #include <hip/hip_runtime.h>

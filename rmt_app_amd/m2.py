@@ -3,7 +3,7 @@
 dispatched by rmtCore.M2Init, PyREMOT/docs/rmtCore.py:239-249).  SURVEY.md section 8(f) rank 3.
 
 Same kernel generator, same steppers and C ABI as N2 (``RMT_MODEL 2`` selects the M2 node
-functions in csrc/n2_kernels.inc): concentrations in kmol/m^3, EOS gas velocity - hence a
+functions in csrc/kernels/21_node_m2.inc): concentrations in kmol/m^3, EOS gas velocity - hence a
 nonlinear Ergun march, solved on the device by Newton sweeps over the affine scan - and the
 catalyst's thermal mass in the energy balance.
 

@@ -8,7 +8,7 @@ of building nested dicts that the RHS re-reads on every call (:3741-3825) it pro
   * ``Mechanism``  - everything that is identical for all members of an ensemble and becomes
                      compile-time constants of the generated kernel (species, stoichiometry, MW,
                      Cp polynomials, heats of reaction, the lowered rate lambdas);
-  * member rows    - 16+S doubles per reactor (layout: csrc/n2_kernels.inc ``M_*``) holding the
+  * member rows    - 16+S doubles per reactor (layout: csrc/kernels/00_config_math.inc ``M_*``) holding the
                      operating-point dependent scalars, pre-combined so the kernel does no
                      redundant work (e.g. the Ergun march coefficient of SURVEY.md section 5).
 """
@@ -27,7 +27,7 @@ PI_CONST = math.pi          # :14
 Tref = 273.15 + 25.00       # :23
 
 MEMBER_FIXED = 16
-# index of each scalar in a member row (must match csrc/n2_kernels.inc)
+# index of each scalar in a member row (must match csrc/kernels/00_config_math.inc)
 MEMBER_FIELDS = {
     "CMAX": 0, "TF": 1, "P0": 2, "THETA_IN": 3, "ALPHA_K": 4, "BETA": 5, "RHO_K": 6,
     "INV_CP0": 7, "F1": 8, "FT": 9, "INV_DZ": 10, "INV_MACOTE": 11, "INV_HECOTE": 12,
@@ -331,7 +331,7 @@ def member_constants(modelInput, mech, zNo):
 
 def member_constants_m2(modelInput, mech, zNo):
     """Model M2 (pbReactor.py:552-700 setup, :845-1165 RHS): the packed row keeps the N2 layout
-    (MEMBER_FIELDS) with the meanings listed above the M2 node functions in csrc/n2_kernels.inc."""
+    (MEMBER_FIELDS) with the meanings listed above the M2 node functions in csrc/kernels/21_node_m2.inc."""
     mi = modelInput
     P = mi['operating-conditions']['pressure']
     T = mi['operating-conditions']['temperature']
@@ -405,7 +405,7 @@ MEMBER1_FIELDS = {
 def member_constants_n1(modelInput, mech):
     """Packed constants of the steady-state model N1: the setup block of runN1
     (pbHomoReactor.py:2694-2900) - identical to runN2's apart from vf = VoFlRa0/CrSeAr - and the
-    h-independent factors of modelEquationN1 (:3017-3314); layout M1_* in csrc/n2_kernels.inc."""
+    h-independent factors of modelEquationN1 (:3017-3314); layout M1_* in csrc/kernels/22_node_n1.inc."""
     nm, _ = member_constants(modelInput, mech, 2)
     mi = modelInput
     ReSpec = mi['reactor']
@@ -443,7 +443,7 @@ def uniform_columns(rows):
 
 def uniform_member_defines(rows, S, vals=None, mask=None):
     """Prelude #defines (RMT_MC_<FIELD>) for the member fields that are identical in every row:
-    they become literals of the kernel (see rmt_load_member in csrc/n2_kernels.inc).  ``vals`` /
+    they become literals of the kernel (see rmt_load_member in csrc/kernels/10_member.inc).  ``vals`` /
     ``mask`` override the locally computed ones (multi-rank ensembles agree on them first)."""
     if vals is None or mask is None:
         vals, mask = uniform_columns(np.asarray(rows, dtype=float).reshape(-1, MEMBER_FIXED + S))

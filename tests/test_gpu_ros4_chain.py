@@ -1,5 +1,5 @@
 """GPU tests of the chained stiff stepper (rmt_n2_ros4_chain): ONE reactor cut into chunks that run on
-different CUs, coupled through tagged-word links (include/rmt_n2.h; csrc/n2_kernels.inc rmt_link_send).
+different CUs, coupled through tagged-word links (include/rmt_n2.h; csrc/kernels/30_lanes_links.inc rmt_link_send).
 Checked against the single-workgroup kernel (an independent path for everything that crosses a chunk
 boundary: pressure / upstream records, Jacobi boundary iterates, error norm, step decision), against the CPU
 oracle's Rosenbrock controller at BASELINE's 4096-node target shape, and for its time-out path."""

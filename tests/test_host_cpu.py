@@ -49,8 +49,13 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert hipbind.lib().rmt_n2_abi_version() == 1
+    # the embedded device template = the per-family files of csrc/kernels/ in the order of kernels/ORDER
     tpl = hipbind.kernel_template()
-    assert tpl == open(os.path.join(ROOT, "rmt_app_amd", "csrc", "n2_kernels.inc")).read()
+    kdir = os.path.join(ROOT, "rmt_app_amd", "csrc", "kernels")
+    names = [ln.split("#", 1)[0].strip() for ln in open(os.path.join(kdir, "ORDER"))]
+    names = [n for n in names if n]
+    assert sorted(names) == sorted(f for f in os.listdir(kdir) if f.endswith(".inc"))
+    assert tpl == "".join(open(os.path.join(kdir, n)).read() for n in names)
 
 
 def test_create_rejects_bad_plans_and_reports_errors():

@@ -80,7 +80,11 @@ extern "C" {
 #define RMT_N2_RING 512
 #define RMT_N2_MAX_CHUNKS 64
 
-/* member row layout: doubles per reactor = 16 + S (see rmt_app_amd/csrc/kernels/00_config_math.inc M_*) */
+/* member row layout: doubles per reactor = 16 + S + NU (see rmt_app_amd/csrc/kernels/00_config_math.inc M_*):
+ * 16 fixed operating-point scalars, S inlet values, then the NU = plan.n_user_params scalar constants of the
+ * user's reaction-rates.VARS that differ between the reactors of the ensemble (the reference copies VARS into
+ * the rate lambdas' namespace on every call, PyREMOT/docs/rmtReaction.py:44-51; the generated kinetics read
+ * them as U[k]) */
 #define RMT_N2_MEMBER_FIXED 16
 
 typedef struct rmt_n2_plan {
@@ -93,10 +97,10 @@ typedef struct rmt_n2_plan {
     int32_t fp32;            /* 1: real = float */
     int32_t block;           /* RMT_BLOCK the code object was generated with */
     int32_t nodes_per_thread;/* RMT_NPT the code object was generated with */
-    int32_t reserved;
+    int32_t n_user_params;   /* NU (RMT_NU of the code object; 0 = every VARS constant is a literal of the kernel) */
     const void* code_object; /* gfx950 code object from rmt_n2_compile (host memory) */
     size_t code_size;
-    const double* members;   /* host [E][16+S] packed constants */
+    const double* members;   /* host [E][16+S+NU] packed constants */
 } rmt_n2_plan;
 
 typedef struct rmt_n2_handle rmt_n2_handle;
@@ -144,7 +148,7 @@ int rmt_n2_ros4(rmt_n2_handle* h, void* y_inout, double t0, double t1, double rt
                 double h0, int64_t max_steps, rmt_n2_stats* stats_out);
 /* (tuning experiments: the environment variable RMT_N2_ROS4_CHUNKS=c overrides the number of chunks rmt_n2_ros4 cuts a
  * reactor into, 1 = one workgroup per reactor; unset = the library's estimate) */
-/* members1: HOST [E][16+S] rows (layout M1_* in csrc/kernels/22_node_n1.inc); out: DEVICE double [E][nout][S+2]
+/* members1: HOST [E][16+S+NU] rows (layout M1_* in csrc/kernels/22_node_n1.inc); out: DEVICE double [E][nout][S+2]
  * (S+1 when iso-thermal) = the state at z* = k/(nout-1); stats: DEVICE [E] */
 int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* out, int nout, double rtol,
                    double atol, double h0, int64_t max_steps, rmt_n2_stats* stats_out);

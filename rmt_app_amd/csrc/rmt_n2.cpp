@@ -38,7 +38,7 @@ static int fail(const char* fmt, ...) {
     } while (0)
 
 struct rmt_n2_handle {
-    int S = 0, V = 0, N = 0, E = 0, fp32 = 0, block = 0, npt = 0, mode = 0, device = 0;
+    int S = 0, V = 0, NU = 0, N = 0, E = 0, fp32 = 0, block = 0, npt = 0, mode = 0, device = 0;
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
@@ -168,6 +168,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     if (p->block < 64 || p->block > 1024 || p->block % 64)
         return fail("block must be a multiple of 64 in [64,1024] (got %d)", p->block);
     if (p->nodes_per_thread < 1) return fail("nodes_per_thread must be >= 1");
+    if (p->n_user_params < 0 || p->n_user_params > 64) return fail("n_user_params must be in [0,64] (got %d)", p->n_user_params);
     if (!p->code_object || !p->code_size || !p->members) return fail("plan lacks code object/members");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -175,6 +176,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     rmt_n2_handle* h = new rmt_n2_handle();
     h->S = p->n_species;
     h->V = p->n_vars;
+    h->NU = p->n_user_params;
     h->N = p->n_nodes;
     h->E = p->n_members;
     h->fp32 = p->fp32;
@@ -211,7 +213,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     if (hipModuleGetFunction(&h->f_ros4_chain, h->module, "rmt_n2_ros4_chain") != hipSuccess) h->f_ros4_chain = nullptr;
     (void)hipGetLastError();
     CREATE_OK(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
+    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S + h->NU) * sizeof(double);
     CREATE_OK(hipMalloc((void**)&h->d_members, mbytes));
     CREATE_OK(hipMemcpy(h->d_members, p->members, mbytes, hipMemcpyHostToDevice));
     CREATE_OK(hipMalloc((void**)&h->d_flags, (size_t)h->E * sizeof(unsigned)));
@@ -256,7 +258,7 @@ extern "C" int rmt_n2_set_mode(rmt_n2_handle* h, int mode) {
 extern "C" int rmt_n2_set_members(rmt_n2_handle* h, const double* members) {
     if (!h || !members) return fail("null argument");
     ON_DEVICE(h);
-    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
+    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S + h->NU) * sizeof(double);
     HIP_OK(hipMemcpyAsync(h->d_members, members, mbytes, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     return 0;
@@ -515,7 +517,7 @@ extern "C" int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* ou
     if (nout < 2 || !(rtol > 0) || !(atol >= 0) || !(h0 > 0)) return fail("bad N1 arguments");
     if (!h->f_n1) return fail("code object has no N1 kernel");
     ON_DEVICE(h);
-    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S) * sizeof(double);
+    const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S + h->NU) * sizeof(double);
     if (!h->d_members1) HIP_OK(hipMalloc((void**)&h->d_members1, mbytes));
     HIP_OK(hipMemcpyAsync(h->d_members1, members1, mbytes, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));

@@ -59,6 +59,95 @@ def expand_members(modelInput, spec):
     return [deep_merge(modelInput, m) for m in spec]
 
 
+def _same_function(f, g):
+    """Two rate lambdas that cannot evaluate differently: the same object, or the same code with the same
+    constants, defaults and closure contents (a member input rebuilt by the same factory)."""
+    if f is g:
+        return True
+    import types
+    if not (isinstance(f, types.FunctionType) and isinstance(g, types.FunctionType)):
+        return False
+    cf, cg = f.__code__, g.__code__
+    if (cf.co_code != cg.co_code or cf.co_consts != cg.co_consts or cf.co_names != cg.co_names
+            or f.__defaults__ != g.__defaults__):
+        return False
+    if (f.__closure__ is None) != (g.__closure__ is None):
+        return False
+    for a, b in zip(f.__closure__ or (), g.__closure__ or ()):
+        try:
+            va, vb = a.cell_contents, b.cell_contents
+        except ValueError:
+            return False
+        if va is not vb and not (isinstance(va, (int, float, str)) and va == vb):
+            return False
+    return all(f.__globals__.get(n) is g.__globals__.get(n) for n in cf.co_names
+               if n in f.__globals__ or n in g.__globals__)
+
+
+def member_parameters(modelInput, member_inputs):
+    """What may differ between the members of an ensemble, checked - and the names of the scalar
+    ``reaction-rates.VARS`` constants that DO differ (they become per-reactor columns of the member row,
+    plan.Mechanism(params=...)).
+
+    The reference runs a sweep as a loop over ``rmtExe`` with ANY modelInput, and its rate evaluation copies
+    the user's VARS constants on every call (PyREMOT/docs/rmtReaction.py:44-51), so members may legitimately
+    differ in operating conditions, feed, reactor, external heat and in kinetic constants.  One launch shares
+    ONE generated kernel, so everything else must agree with the base input; a member that differs in
+    something the member row cannot express raises ValueError naming the member and the key - it must never
+    silently run with the base mechanism."""
+    from .lowering import is_scalar_constant
+    base = modelInput
+    brr = base['reaction-rates']
+    bV, bR = brr['VARS'], brr['RATES']
+    varying = []
+
+    def bad(e, key, why):
+        raise ValueError("ensemble member %d differs from the base input in %s: %s - members of one launch share "
+                         "the compiled mechanism (run it as its own rmtExe call)" % (e, key, why))
+
+    for e, mi in enumerate(member_inputs):
+        if mi is base:
+            continue
+        if mi.get('model') != base.get('model'):
+            bad(e, "'model'", "%r vs %r" % (mi.get('model'), base.get('model')))
+        if list(mi['feed']['components']['shell']) != list(base['feed']['components']['shell']):
+            bad(e, "feed.components.shell", "%r" % (mi['feed']['components']['shell'],))
+        oc, boc = mi['operating-conditions'], base['operating-conditions']
+        for key in ('process-type', 'period'):
+            if oc.get(key) != boc.get(key):
+                bad(e, "operating-conditions.%s" % key, "%r vs %r" % (oc.get(key), boc.get(key)))
+        if mi['reactions'] is not base['reactions'] and list(mi['reactions'].items()) != list(base['reactions'].items()):
+            bad(e, "'reactions'", "%r" % (dict(mi['reactions']),))
+        rr = mi['reaction-rates']
+        if rr is brr:
+            continue
+        V, R = rr['VARS'], rr['RATES']
+        if list(R) != list(bR) or not all(_same_function(R[k], bR[k]) for k in bR):
+            bad(e, "reaction-rates.RATES", "different rate expressions")
+        if V is bV:
+            continue
+        if list(V) != list(bV):
+            bad(e, "reaction-rates.VARS", "keys %r vs %r (the evaluation order is part of the mechanism)" % (list(V), list(bV)))
+        for k in bV:
+            a, b = V[k], bV[k]
+            if a is b:
+                continue
+            if is_scalar_constant(a) and is_scalar_constant(b):
+                if float(a) != float(b) and k not in varying:
+                    varying.append(k)
+            elif not _same_function(a, b):
+                if not (callable(a) or callable(b)):
+                    try:
+                        same = bool(np.all(np.asarray(a) == np.asarray(b)))
+                    except Exception:
+                        same = False
+                    if same:
+                        continue
+                bad(e, "reaction-rates.VARS[%r]" % k, "only scalar constants may vary between members")
+    # keep the VARS order: the parameter columns are then independent of which member differed first
+    return [k for k in bV if k in varying]
+
+
 def shard(n_members, world, rank):
     """Contiguous block [lo, hi) of members owned by ``rank`` (sizes differ by at most one)."""
     base, extra = divmod(n_members, world)
@@ -98,6 +187,35 @@ def gather_rows(local, counts, dst=0, group=None):
     return None
 
 
+def agree(err, group=None, device=None):
+    """Every rank calls this with its local exception (or None) after a rank-LOCAL phase (packing, compiling,
+    creating the device, a launch): if any rank failed, ALL ranks raise - nobody is left waiting in the next
+    collective.  The phase itself must not contain collectives."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    bad = torch.tensor([0 if err is None else rank + 1], dtype=torch.int64, device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if err is not None:
+        raise err
+    if int(bad.item()):
+        raise RuntimeError("ensemble job failed on rank %d (its exception is raised there)" % (int(bad.item()) - 1))
+
+
+def guarded(sync, fn, *args, **kw):
+    """Run a rank-local phase; with ``sync`` (a RankSync) its failure on any rank is raised on every rank."""
+    if sync is None:
+        return fn(*args, **kw)
+    err, out = None, None
+    try:
+        out = fn(*args, **kw)
+    except Exception as e:          # noqa: BLE001 - re-raised on every rank by agree()
+        err = e
+    sync.agree(err)
+    return out
+
+
 class RankSync:
     """The process group as seen by rmtExe's ensemble path (run_n2 / run_m2 / run_n1) when
     torch.distributed is initialised with more than one rank: which members this rank owns, and the
@@ -121,15 +239,7 @@ class RankSync:
     def agree(self, err):
         """Every rank calls this once per output interval with its local exception (or None); if any
         rank failed, ALL ranks raise - nobody is left waiting in the next gather."""
-        import torch
-        import torch.distributed as dist
-        bad = torch.tensor([0 if err is None else self.rank + 1], dtype=torch.int64, device=self.device)
-        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.group)
-        if err is not None:
-            raise err
-        if int(bad.item()):
-            raise RuntimeError("ensemble integration failed on rank %d (its exception is raised there)"
-                               % (int(bad.item()) - 1))
+        agree(err, self.group, self.device)
 
     def max_int(self, v):
         import torch
@@ -186,10 +296,26 @@ class DistributedEnsemble:
         m2 = getattr(mech, "model", "N2") == "M2"          # same row layout, different meanings (plan.py)
         pack, init = ((plan.member_constants_m2, plan.initial_state_m2) if m2
                       else (plan.member_constants, plan.initial_state))
-        pairs = [pack(mi, mech, zNo) for mi in mine]
-        self.named = [nm for nm, _ in pairs]
-        self.rows = np.array([r for _, r in pairs]).reshape(len(mine), plan.MEMBER_FIXED + mech.S)
-        self.IV = np.array([init(nm, mech, zNo) for nm in self.named]).reshape(len(mine), mech.V*zNo)
+        multi = dist.is_initialized() and self.world > 1
+
+        def local_phase(fn):        # a failure of one rank's packing / compile is raised on every rank
+            if not multi:
+                return fn()
+            err, out = None, None
+            try:
+                out = fn()
+            except Exception as e:  # noqa: BLE001
+                err = e
+            agree(err, group, device)
+            return out
+
+        def pack_mine():
+            pairs = [pack(mi, mech, zNo) for mi in mine]
+            named = [nm for nm, _ in pairs]
+            rows = np.array([r for _, r in pairs]).reshape(len(mine), mech.row_width)
+            IV = np.array([init(nm, mech, zNo) for nm in named]).reshape(len(mine), mech.V*zNo)
+            return named, rows, IV
+        self.named, self.rows, self.IV = local_phase(pack_mine)
         # member fields that are identical over the WHOLE ensemble become kernel literals: agree on
         # them across ranks (rank 0's values; a column counts only if every rank finds it uniform
         # and equal to rank 0's)
@@ -205,7 +331,8 @@ class DistributedEnsemble:
             vals, mask = v0, ok.cpu().numpy().astype(bool)
         self.member_defines = plan.uniform_member_defines(None, mech.S, vals, mask)
         # rank 0 compiles; everyone receives the identical code object
-        code = compile_fn(self.member_defines) if (self.rank == 0 and compile_fn is not None) else b""
+        code = local_phase(lambda: compile_fn(self.member_defines)
+                           if (self.rank == 0 and compile_fn is not None) else b"")
         if dist.is_initialized():
             code = broadcast_bytes(code, 0, group, device)
         self.code = code

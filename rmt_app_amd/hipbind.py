@@ -24,7 +24,7 @@ class Plan(C.Structure):
         ("abi_version", C.c_int32), ("n_species", C.c_int32), ("n_reactions", C.c_int32),
         ("n_vars", C.c_int32), ("n_nodes", C.c_int32), ("n_members", C.c_int32),
         ("fp32", C.c_int32), ("block", C.c_int32), ("nodes_per_thread", C.c_int32),
-        ("reserved", C.c_int32),
+        ("n_user_params", C.c_int32),
         ("code_object", C.c_void_p), ("code_size", C.c_size_t), ("members", C.POINTER(C.c_double)),
     ]
 

@@ -362,7 +362,7 @@ class Lowered:
         return h.hexdigest()
 
     # ---- evaluation on the host (used by tests to check the trace itself, not by the product path)
-    def evaluate(self, T, P, x, C):
+    def evaluate(self, T, P, x, C, U=()):
         env = {}
         for i in sorted(self.live):
             op, a, b = self.g.nodes[i]
@@ -370,7 +370,7 @@ class Lowered:
                 env[i] = self.g.cval(i)
             elif op == "in":
                 env[i] = {"T": T, "P": P}.get(a) if a in ("T", "P") else (
-                    x[int(a[1:])] if a[0] == "x" else C[int(a[1:])])
+                    x[int(a[1:])] if a[0] == "x" else (U[int(a[1:])] if a[0] == "u" else C[int(a[1:])]))
             elif op == "powi":
                 env[i] = env[a]**b
             elif op in ("add", "sub", "mul", "div", "pow", "min", "max"):
@@ -577,7 +577,8 @@ class Lowered:
                 new[i] = g2._mk(op, new[a].i, new[b].i)
         n_primal = len(g2.nodes)
         if wrt is None:
-            wrt = sorted({g.nodes[i][1] for i in self.live if g.nodes[i][0] == "in" and g.nodes[i][1] != "P"})
+            wrt = sorted({g.nodes[i][1] for i in self.live if g.nodes[i][0] == "in" and g.nodes[i][1] != "P"
+                          and g.nodes[i][1][0] != "u"})        # u<k>: per-reactor parameters, frozen like P
         wrt = list(wrt)
 
         def c(v):
@@ -767,7 +768,8 @@ class Lowered:
                 name[i] = lit(g.cval(i))
                 continue
             if op == "in":
-                name[i] = a if a in ("T", "P") else ("x[%s]" % a[1:] if a[0] == "x" else "C[%s]" % a[1:])
+                name[i] = a if a in ("T", "P") else ("x[%s]" % a[1:] if a[0] == "x" else (
+                    "U[%s]" % a[1:] if a[0] == "u" else "C[%s]" % a[1:]))
                 continue
             v = "v%d" % i
             A = name[a]
@@ -871,8 +873,9 @@ class Lowered:
         return self._table_decl + (
             "template <typename FL>\n"
             "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
-            "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r, FL& flag) {\n"
-            "    (void)invT;\n%s\n%s\n}\n"
+            "        const real* __restrict__ x, const real* __restrict__ C, const real* __restrict__ U,\n"
+            "        real* __restrict__ r, FL& flag) {\n"
+            "    (void)invT; (void)U;\n%s\n%s\n}\n"
             % (fname, body, outs))
 
 
@@ -888,9 +891,9 @@ class Gradient(Lowered):
         Lowered.__init__(self, graph, flat, nspecies)
         self.rate_outputs = list(outputs)
 
-    def evaluate_all(self, T, P, x, C):
+    def evaluate_all(self, T, P, x, C, U=()):
         """(rates, [{input: d rate / d input}]) on the host - for the tests of the gradient itself."""
-        vals = self.evaluate(T, P, x, C)
+        vals = self.evaluate(T, P, x, C, U)
         R = self.n_rates
         out, pos = [], R
         for p in self.partial:
@@ -915,17 +918,30 @@ class Gradient(Lowered):
         return (
             "template <typename FL>\n"
             "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
-            "        const real* __restrict__ x, const real* __restrict__ C, real* __restrict__ r,\n"
+            "        const real* __restrict__ x, const real* __restrict__ C, const real* __restrict__ U,\n"
+            "        real* __restrict__ r,\n"
             "        real* __restrict__ drdT, real (*__restrict__ drdx)[RMT_S], real (*__restrict__ drdC)[RMT_S],%s FL& flag) {\n"
-            "    (void)invT;\n%s\n%s\n}\n"
+            "    (void)invT; (void)U;\n%s\n%s\n}\n"
             % (fname, " real* __restrict__ drdP," if with_p else "", "\n".join(lines), "\n".join(outs)))
 
 
-def trace(VARS, RATES, nspecies, R_CONST=8.314472, fixed=None):
+def is_scalar_constant(v):
+    """A VARS entry that reactionRateExe copies as a plain number (rmtReaction.py:44-51)."""
+    return _num(v) or (isinstance(v, np.ndarray) and v.ndim == 0 and v.dtype.kind in "fiu")
+
+
+def trace(VARS, RATES, nspecies, R_CONST=8.314472, fixed=None, params=()):
     """Symbolic run of reactionRateExe (rmtReaction.py:27-58).  ``fixed`` optionally binds inputs
-    (e.g. {"T": 523.0}) to literals so that everything depending only on them is folded."""
+    (e.g. {"T": 523.0}) to literals so that everything depending only on them is folded.
+    ``params``: names of scalar VARS entries that stay SYMBOLIC - input ``u<k>`` for params[k] - instead of
+    being folded as literals: per-reactor kinetic parameters of an ensemble (a sweep over a catalyst density,
+    a pre-exponential factor, an activation energy), read by the kernel from the member row."""
     g = Graph()
     fixed = fixed or {}
+    params = list(params)
+    for nm in params:
+        if nm not in VARS or not is_scalar_constant(VARS[nm]):
+            raise LoweringError("VARS[%r] cannot be a per-reactor parameter: it is not a scalar constant" % (nm,))
 
     def leaf(nm):
         return g.const(fixed[nm]) if nm in fixed else g.inp(nm)
@@ -948,6 +964,8 @@ def trace(VARS, RATES, nspecies, R_CONST=8.314472, fixed=None):
                 raise
             except Exception as e:
                 raise LoweringError("cannot trace VARS[%r]: %s: %s" % (k, type(e).__name__, e)) from e
+        elif k in params:
+            exe[k] = g.inp("u%d" % params.index(k))
         else:
             exe[k] = v
     outs = []

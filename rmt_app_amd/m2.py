@@ -16,8 +16,8 @@ from timeit import default_timer as timer
 import numpy as np
 
 from . import plan
-from .n2 import (ROUND_FUN_ACCURACY, integrate_intervals, open_auto, open_members, resolve_ivp, rk45_geometry,
-                 ros4_block)
+from .n2 import (ROUND_FUN_ACCURACY, integrate_intervals, mechanism_for, open_auto, open_members, resolve_ivp,
+                 rk45_geometry, ros4_block)
 from .settings import solverSetting
 
 
@@ -52,9 +52,9 @@ def run_m2(modelInput, members_inputs=None):
     if cfg.get('dtype', 'fp64') not in ('fp64', 'float64'):
         raise ValueError("model M2 is built in fp64 only")
     opT = modelInput['operating-conditions']['period']
-    mech = plan.Mechanism(modelInput)
     inputs = list(members_inputs) if members_inputs else [modelInput]
-    from .ensemble import active_ranks
+    mech = mechanism_for(modelInput, inputs, cfg)
+    from .ensemble import active_ranks, guarded
     sync = active_ranks(len(inputs)) if members_inputs else None       # one rank of a torchrun job?
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
@@ -73,7 +73,7 @@ def run_m2(modelInput, members_inputs=None):
     n_pack = len(inputs) if packer else 0
     opTSpan = np.linspace(0, opT, tNo + 1)                          # :695
     try:
-        y = dev.to_device(IV)
+        y = guarded(sync, dev.to_device, IV)
         packs = [[] for _ in range(n_pack)]
 
         def on_interval(i, t1, Yh):

@@ -3,13 +3,12 @@
 [c_i, P*, theta] along the dimensionless length with solve_ivp(LSODA) and samples
 t_eval = linspace(0, 1, zNo+1) (:2931); here one launch integrates every member of an ensemble
 (one reactor per lane) with the RODAS4 scheme of the N2 stiff stepper."""
-import ctypes as C
 from timeit import default_timer as timer
 
 import numpy as np
 
-from . import hipbind, plan
-from .n2 import N2Device
+from . import plan
+from . import n2 as _n2
 from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
 
 
@@ -50,36 +49,30 @@ def run_n1(modelInput, members_inputs=None):
     displayResult = cfg['display-result'] == "True"
     zNo = int(cfg.get('zNo', solverSetting['N1']['zNo']))
     nout = zNo + 1
-    mech = plan.Mechanism(modelInput)
     all_inputs = list(members_inputs) if members_inputs else [modelInput]
-    # as one rank of a torch.distributed job: integrate this rank's contiguous block of profiles
-    from .ensemble import active_ranks
+    mech = _n2.mechanism_for(modelInput, all_inputs, cfg)
+    # as one rank of a torch.distributed job: integrate this rank's contiguous block of profiles.  Every
+    # rank-local phase (packing, device creation, the launch + status read) runs under ensemble.guarded: a failure
+    # on one rank is raised on every rank before the next collective.
+    from .ensemble import active_ranks, guarded
     sync = active_ranks(len(all_inputs)) if members_inputs else None
     inputs = all_inputs if sync is None else all_inputs[sync.lo:sync.hi]
-    pairs = [plan.member_constants_n1(mi, mech) for mi in inputs]
-    rows1 = np.ascontiguousarray(np.array([r for _, r in pairs]))
-    # the handle is an N2 handle (same generated module); its N2 member rows are not used here
-    dummy = np.array([plan.member_constants(mi, mech, 64)[1] for mi in inputs])
-    dev = N2Device(mech, dummy, 64, block=64, npt=1, specialize=False, features=("n1",))
+
+    def pack_and_open():
+        pairs = [plan.member_constants_n1(mi, mech) for mi in inputs]
+        rows1 = np.ascontiguousarray(np.array([r for _, r in pairs]))
+        # the handle is an N2 handle (same generated module); its N2 member rows are not used here
+        dummy = np.array([plan.member_constants(mi, mech, 64)[1] for mi in inputs])
+        return pairs, rows1, _n2.device_cls()(mech, dummy, 64, block=64, npt=1, specialize=False, features=("n1",))
+    pairs, rows1, dev = guarded(sync, pack_and_open)
     try:
-        torch = dev.torch
-        V1 = mech.S + (1 if mech.iso else 2)
-        out = torch.zeros((len(inputs), nout, V1), dtype=torch.float64, device=dev.device)
-        hipbind.check(hipbind.lib().rmt_n1_profile(
-            dev.h, rows1.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(out.data_ptr()), nout,
-            float(cfg.get('rtol', DEVICE_DEFAULTS['n1-rtol'])), float(cfg.get('atol', DEVICE_DEFAULTS['n1-atol'])),
-            float(cfg.get('h0', 1e-6)), int(cfg.get('max-steps', 10**7)), C.c_void_p(dev._stats.data_ptr())))
-        if sync is None:
+        def launch():
+            out = dev.n1_profile(rows1, nout, float(cfg.get('rtol', DEVICE_DEFAULTS['n1-rtol'])),
+                                 float(cfg.get('atol', DEVICE_DEFAULTS['n1-atol'])), float(cfg.get('h0', 1e-6)),
+                                 int(cfg.get('max-steps', 10**7)))
             dev.raise_on_flags()
-        else:
-            err = None
-            try:
-                dev.raise_on_flags()
-            except Exception as e:          # noqa: BLE001 - raised on every rank by agree()
-                err = e
-            sync.agree(err)
-        stats = dev.rk45_stats()
-        U = out.cpu().numpy()
+            return dev.rk45_stats(), out
+        stats, U = guarded(sync, launch)
     finally:
         dev.close()
     if sync is not None:                    # rank 0 returns every member's profile, the other ranks None

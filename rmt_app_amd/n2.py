@@ -158,7 +158,7 @@ class N2Device:
         members = np.ascontiguousarray(members, dtype=np.float64)
         if members.ndim == 1:
             members = members.reshape(1, -1)
-        assert members.shape[1] == plan.MEMBER_FIXED + mech.S
+        assert members.shape[1] == mech.row_width, "member rows must hold 16 + S + NU doubles"
         self.E = members.shape[0]
         self.members = members
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -176,6 +176,7 @@ class N2Device:
         p.n_species, p.n_reactions, p.n_vars = mech.S, mech.R, mech.V
         p.n_nodes, p.n_members, p.fp32 = self.N, self.E, int(self.fp32)
         p.block, p.nodes_per_thread = self.block, self.npt
+        p.n_user_params = mech.NU
         p.code_object = C.cast(self._code, C.c_void_p)
         p.code_size = len(code)
         p.members = members.ctypes.data_as(C.POINTER(C.c_double))
@@ -203,7 +204,7 @@ class N2Device:
             raise hipbind.RmtN2Error("this kernel was specialised on its member rows "
                                      "(N2Device(..., specialize=False) keeps them run-time)")
         members = np.ascontiguousarray(members, dtype=np.float64).reshape(self.E, -1)
-        assert members.shape[1] == plan.MEMBER_FIXED + self.mech.S
+        assert members.shape[1] == self.mech.row_width
         self.members = members
         hipbind.check(hipbind.lib().rmt_n2_set_members(self.h, members.ctypes.data_as(C.POINTER(C.c_double))))
 
@@ -265,6 +266,18 @@ class N2Device:
         hipbind.check(hipbind.lib().rmt_n2_ros4(self.h, C.c_void_p(y.data_ptr()), float(t0), float(t1),
                                                 float(rtol), float(atol), float(h0), int(max_steps),
                                                 C.c_void_p(self._stats.data_ptr())))
+
+    def n1_profile(self, rows1, nout, rtol, atol, h0, max_steps):
+        """Steady-state model N1 (needs features=("n1",)): one profile per member row of ``rows1`` (layout M1_*),
+        sampled at z* = k/(nout-1); returns the host array [E][nout][S+2] (S+1 when iso-thermal)."""
+        torch = self.torch
+        rows1 = np.ascontiguousarray(rows1, dtype=np.float64).reshape(self.E, self.mech.row_width)
+        V1 = self.mech.S + (1 if self.mech.iso else 2)
+        out = torch.zeros((self.E, int(nout), V1), dtype=torch.float64, device=self.device)
+        hipbind.check(hipbind.lib().rmt_n1_profile(
+            self.h, rows1.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(out.data_ptr()), int(nout),
+            float(rtol), float(atol), float(h0), int(max_steps), C.c_void_p(self._stats.data_ptr())))
+        return out.cpu().numpy()
 
     def rk45_stats(self):
         raw = self._stats.cpu().numpy()
@@ -500,6 +513,25 @@ def device_arch():
     return "gfx950"
 
 
+def device_cls():
+    """The device class the ensemble path instantiates (looked up at call time: the gloo CPU tests put a
+    host-emulation stand-in here, tests/emu_device.py)."""
+    return N2Device
+
+
+def mechanism_for(modelInput, inputs, cfg):
+    """The ONE compiled mechanism of a launch: the base input's, with every scalar VARS constant that differs
+    between the members (ensemble.member_parameters - which also refuses members that differ in anything the
+    member row cannot express) or that solver-config "vars-as-parameters" names kept as a per-reactor parameter."""
+    params = list(cfg.get('vars-as-parameters', ()))
+    if len(inputs) > 1 or inputs[0] is not modelInput:
+        from .ensemble import member_parameters
+        varying = member_parameters(modelInput, inputs)
+        VARS = modelInput['reaction-rates']['VARS']
+        params = [k for k in VARS if k in params or k in varying] + [k for k in params if k not in VARS]
+    return plan.Mechanism(modelInput, params=params)
+
+
 def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=None, npt=None, defines=None,
                  features=()):
     """Device + initial state for the members THIS process integrates.
@@ -512,9 +544,12 @@ def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=Non
         pairs = [pack(mi, mech, zNo) for mi in inputs]
         rows = np.array([r for _, r in pairs])
         IV = np.array([init(nm, mech, zNo) for nm, _ in pairs])
-        dev = N2Device(mech, rows, zNo, fp32=fp32, block=block, npt=npt, defines=defines, features=features)
+        dev = device_cls()(mech, rows, zNo, fp32=fp32, block=block, npt=npt, defines=defines, features=features)
         return dev, [nm for nm, _ in pairs], IV
-    from .ensemble import DistributedEnsemble
+    # Multi-rank: every rank-LOCAL phase (packing, the rank-0 compile inside DistributedEnsemble, loading the
+    # module and allocating on the device) runs under ensemble.guarded / agree: a failure on one rank is raised
+    # on every rank instead of leaving the others in the next collective until the backend's timeout.
+    from .ensemble import DistributedEnsemble, guarded
     E_geo = max(sync.counts)                       # one geometry for all ranks (block sizes differ by <= 1 member)
     b, n = choose_geometry(zNo, mech.V, fp32, E_geo)
     block, npt = int(block or b), int(npt or n)
@@ -522,14 +557,15 @@ def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=Non
     for f in features:
         defs[FEATURE_DEFINES[f]] = "1"
     if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in defs:
-        mine = np.array([pack(mi, mech, zNo)[1] for mi in inputs[sync.lo:sync.hi]])
-        defs["RMT_M2_NEWTON"] = str(sync.max_int(plan.m2_newton_sweeps(mine, mech, zNo)))
+        sweeps = guarded(sync, lambda: plan.m2_newton_sweeps(
+            np.array([pack(mi, mech, zNo)[1] for mi in inputs[sync.lo:sync.hi]]), mech, zNo))
+        defs["RMT_M2_NEWTON"] = str(sync.max_int(sweeps))
     arch = device_arch()
     ens = DistributedEnsemble(
         mech, inputs, zNo, group=sync.group, device=sync.device,
         compile_fn=lambda mdef: compile_mechanism(mech, zNo, fp32, block, npt, None, {**defs, **mdef}, arch, E_geo))
-    dev = N2Device(mech, ens.rows, zNo, fp32=fp32, block=block, npt=npt, defines={**defs, **ens.member_defines},
-                   specialize=False, code=ens.code, features=features)
+    dev = guarded(sync, device_cls(), mech, ens.rows, zNo, fp32=fp32, block=block, npt=npt,
+                  defines={**defs, **ens.member_defines}, specialize=False, code=ens.code, features=features)
     return dev, ens.named, ens.IV
 
 
@@ -663,9 +699,9 @@ def run_n2(modelInput, members_inputs=None):
     opT = modelInput['operating-conditions']['period']
     modelId = modelInput['model']
 
-    mech = plan.Mechanism(modelInput)
     inputs = list(members_inputs) if members_inputs else [modelInput]
-    from .ensemble import active_ranks
+    mech = mechanism_for(modelInput, inputs, cfg)
+    from .ensemble import active_ranks, guarded
     sync = active_ranks(len(inputs)) if members_inputs else None       # one rank of a torchrun job?
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
@@ -684,12 +720,12 @@ def run_n2(modelInput, members_inputs=None):
                                             features=("ros4",) if ivp == "hip-ros4" else ())
     # the process that returns the results (rank 0, or the only one) packs EVERY member
     packer = sync is None or sync.rank == 0
-    if sync is None:
-        named = named_local
-    else:
-        named = [plan.member_constants(mi, mech, zNo)[0] for mi in inputs] if packer else []
     try:
-        y = dev.to_device(IV)
+        if sync is None:
+            named = named_local
+        else:
+            named = guarded(sync, lambda: [plan.member_constants(mi, mech, zNo)[0] for mi in inputs] if packer else [])
+        y = guarded(sync, dev.to_device, IV)
         packs = [[] for _ in named]
 
         def on_interval(i, t1, Yh):

@@ -8,9 +8,14 @@ of building nested dicts that the RHS re-reads on every call (:3741-3825) it pro
   * ``Mechanism``  - everything that is identical for all members of an ensemble and becomes
                      compile-time constants of the generated kernel (species, stoichiometry, MW,
                      Cp polynomials, heats of reaction, the lowered rate lambdas);
-  * member rows    - 16+S doubles per reactor (layout: csrc/kernels/00_config_math.inc ``M_*``) holding the
+  * member rows    - 16+S(+NU) doubles per reactor (layout: csrc/kernels/00_config_math.inc ``M_*``) holding the
                      operating-point dependent scalars, pre-combined so the kernel does no
-                     redundant work (e.g. the Ergun march coefficient of SURVEY.md section 5).
+                     redundant work (e.g. the Ergun march coefficient of SURVEY.md section 5), followed by
+                     the NU scalar ``reaction-rates.VARS`` entries that differ between the members of an
+                     ensemble (``Mechanism(params=...)``): the reference copies the user's VARS constants into
+                     the namespace on every call (rmtReaction.py:44-51), so a sweep over a catalyst density or
+                     an Arrhenius constant is an ordinary sweep there - here those entries stay symbolic in the
+                     lowering and are read from the member row.
 """
 import hashlib
 import math
@@ -90,8 +95,12 @@ class Mechanism:
 
     optimize = True     # class-wide switch: emit the strength-reduced kinetics DAG
 
-    def __init__(self, modelInput):
+    def __init__(self, modelInput, params=()):
+        """``params``: names of scalar ``reaction-rates.VARS`` entries that are per-reactor parameters (columns
+        16+S.. of the member row) instead of literals of the generated kernel."""
         mi = modelInput
+        self.params = tuple(params)
+        self.NU = len(self.params)
         self.compList = list(mi['feed']['components']['shell'])
         for s in build_component_list(mi['feed']['components']):
             if s not in compdb.componentSymbolList:
@@ -122,7 +131,7 @@ class Mechanism:
         self.cp_ref = np.array([compdb.cp_value(s, Tref) for s in self.compList])
         self.StHeRe25 = np.array([self._standard_heat(expr) for expr in self.reactionDict.values()])
         rr = mi['reaction-rates']
-        self.lowered = trace(rr['VARS'], rr['RATES'], self.S, R_CONST)
+        self.lowered = trace(rr['VARS'], rr['RATES'], self.S, R_CONST, params=self.params)
         if len(self.lowered.outputs) != self.R:
             raise ValueError("%d rate expressions for %d reactions" % (len(self.lowered.outputs), self.R))
 
@@ -145,6 +154,7 @@ class Mechanism:
             "// generated by rmt_app_amd.plan.Mechanism.prelude - do not edit",
             "#define RMT_S %d" % S,
             "#define RMT_R %d" % R,
+            "#define RMT_NU %d" % self.NU,
             "#define RMT_ISO %d" % (1 if self.iso else 0),
             "#define RMT_MODEL %d" % (2 if self.model == "M2" else 0),
             "#define RMT_FP32 %d" % (1 if fp32 else 0),
@@ -253,6 +263,20 @@ class Mechanism:
         body = template.replace("RMT_KINETICS_SOURCE", kin, 1)
         return self.prelude(fp32, block, npt, lds_state, defines) + body
 
+    @property
+    def row_width(self):
+        """doubles per member row: 16 fixed scalars, S inlet values, NU user parameters."""
+        return MEMBER_FIXED + self.S + self.NU
+
+    def new_row(self, modelInput):
+        """Zeroed member row with the user-parameter columns (the member's own values of ``self.params``) filled."""
+        row = np.zeros(self.row_width)
+        if self.NU:
+            VARS = modelInput['reaction-rates']['VARS']
+            for k, nm in enumerate(self.params):
+                row[MEMBER_FIXED + self.S + k] = float(VARS[nm])
+        return row
+
     def digest(self, template, fp32, block, npt, lds_state=None, defines=None):
         h = hashlib.sha256()
         h.update(self.source(template, fp32, block, npt, lds_state, defines).encode())
@@ -306,7 +330,7 @@ def member_constants(modelInput, mech, zNo):
         "GaMaCoTe0": GaMaCoTe0, "GaHeCoTe0": GaHeCoTe0, "EfHeTrAr": a, "Cmax": Cmax,
         "P0": P, "T0": T, "VoFlRa0": VoFlRa0, "U": U, "Tm": Tm,
     }
-    row = np.zeros(MEMBER_FIXED + mech.S)
+    row = mech.new_row(mi)
     F = MEMBER_FIELDS
     row[F["CMAX"]] = Cmax
     row[F["TF"]] = Tf
@@ -352,7 +376,7 @@ def member_constants_m2(modelInput, mech, zNo):
     ergD = (1 - BeVoFr)/(BeVoFr**3)
     named = {"CrSeAr": CrSeAr, "SpCoi0": SpCoi0, "SpCo0": SpCo0, "GaMiVi": GaMiVi, "dz": dz,
              "P0": P, "T0": T, "VoFlRa0": VoFlRa0, "ReLe": ReLe, "InGaVe0": InGaVe0}
-    row = np.zeros(MEMBER_FIXED + mech.S)
+    row = mech.new_row(mi)
     F = MEMBER_FIELDS
     row[F["CMAX"]] = 1.0
     row[F["TF"]] = T
@@ -375,7 +399,7 @@ def m2_newton_sweeps(rows, mech, zNo):
     """Newton sweeps the M2 pressure march needs (RMT_M2_NEWTON), from the relative pressure drop
     of the feed state over the bed (largest over the members): the error contracts like
     e' ~ 0.01..0.05 e^2 starting from e0 = drop, and the kernel accepts a last update < 3e-7."""
-    rows = np.asarray(rows, dtype=float).reshape(-1, MEMBER_FIXED + mech.S)
+    rows = np.asarray(rows, dtype=float).reshape(-1, mech.row_width)
     F = MEMBER_FIELDS
     worst = 0.0
     for r in rows:
@@ -416,7 +440,7 @@ def member_constants_n1(modelInput, mech):
     GaHeCoTe0 = (nm["GaDe0"]*vf*nm["Tf"]*(nm["Cpf"]/nm["MiMoWe0"])/zf)
     ergB = ((1 - BeVoFr)**2)/(BeVoFr**3)
     ergD = (1 - BeVoFr)/(BeVoFr**3)
-    row = np.zeros(MEMBER_FIXED + mech.S)
+    row = mech.new_row(mi)
     F = MEMBER1_FIELDS
     row[F["CMAX"]], row[F["TF"]], row[F["PF"]], row[F["SPCO0"]] = nm["Cmax"], nm["Tf"], Pf, nm["SpCo0"]
     row[F["ERGA"]] = 150*nm["GaMiVi"]*ergB/(PaDi**2)/(Pf/zf)             # :3206-3220
@@ -444,9 +468,11 @@ def uniform_columns(rows):
 def uniform_member_defines(rows, S, vals=None, mask=None):
     """Prelude #defines (RMT_MC_<FIELD>) for the member fields that are identical in every row:
     they become literals of the kernel (see rmt_load_member in csrc/kernels/10_member.inc).  ``vals`` /
-    ``mask`` override the locally computed ones (multi-rank ensembles agree on them first)."""
+    ``mask`` override the locally computed ones (multi-rank ensembles agree on them first).  ``rows``: 2-D
+    [E][row width]; the user-parameter columns beyond 16+S are always read at run time."""
     if vals is None or mask is None:
-        vals, mask = uniform_columns(np.asarray(rows, dtype=float).reshape(-1, MEMBER_FIXED + S))
+        rows = np.asarray(rows, dtype=float)
+        vals, mask = uniform_columns(rows if rows.ndim == 2 else rows.reshape(1, -1))
     out = {}
     for name, idx in MEMBER_FIELDS.items():
         if name == "CIN":

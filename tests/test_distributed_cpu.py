@@ -186,3 +186,49 @@ def test_rmtexe_failure_on_one_rank_raises_on_all(tmp_path):
                        start_method="spawn")
     r0, r1 = open(out + ".0").read(), open(out + ".1").read()
     assert r1 == "FloatingPointError" and r0 == "RuntimeError", (r0, r1)
+
+
+# ----------------------------------------------------------------------------- rank-local failures outside the launches
+def _construct_fail_worker(rank, world, port, out_path, where):
+    """One rank's device stand-in fails at CONSTRUCTION (module load / allocation on a real device) or when the
+    state is moved to the device: every rank must raise before the next collective, none may sit in it."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        import emu_device
+        from rmt_app_amd import n2, rmtExe
+
+        class Failing(emu_device.EmuDevice):
+            def __init__(self, *a, **k):
+                if where == "create" and rank == 1:
+                    raise MemoryError("hipMalloc failed (simulated) on rank 1")
+                super().__init__(*a, **k)
+
+            def to_device(self, y):
+                if where == "to_device" and rank == 1:
+                    raise MemoryError("H2D copy failed (simulated) on rank 1")
+                return super().to_device(y)
+        real_device, n2.N2Device = n2.N2Device, Failing
+        try:
+            rmtExe(_exe_input("N2"))
+            raised = "none"
+        except (MemoryError, RuntimeError) as e:
+            raised = "%s: %s" % (type(e).__name__, e)
+        finally:
+            n2.N2Device = real_device
+        with open("%s.%d" % (out_path, rank), "w") as f:
+            f.write(raised)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("where", ["create", "to_device"])
+def test_rank_local_failure_before_the_first_launch_raises_on_all_ranks(tmp_path, where):
+    out = str(tmp_path / "cfail")
+    mp.start_processes(_construct_fail_worker, args=(2, _free_port(), out, where), nprocs=2, join=True,
+                       start_method="spawn")
+    r0, r1 = open(out + ".0").read(), open(out + ".1").read()
+    assert r1.startswith("MemoryError") and "rank 1" in r1, r1
+    assert r0.startswith("RuntimeError") and "failed on rank 1" in r0, r0

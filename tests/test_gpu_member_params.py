@@ -1,0 +1,134 @@
+"""GPU: ensemble members that differ in kinetic constants (scalar reaction-rates.VARS entries) run in ONE launch
+with those constants as per-reactor columns of the member row - the device counterpart of the reference's loop
+over rmtExe with differing VARS (PyREMOT/docs/rmtReaction.py:44-51) - and a member that differs in anything else
+raises.  Parity: the oracle evaluates every member with its OWN lambdas, like the reference would."""
+import numpy as np
+import pytest
+
+import inputs as INP
+from oracle import n2_oracle as O
+from rmt_app_amd import ensemble as ENS
+from rmt_app_amd import plan, rmtExe
+from rmt_app_amd.n2 import N2Device
+from parity import rowwise_err
+
+pytestmark = pytest.mark.gpu
+CABEDE = [1171.2, 500.0, 1800.0]
+
+
+def _members(base, values=CABEDE, key="CaBeDe"):
+    return ENS.expand_members(base, [{"reaction-rates": {"VARS": {key: v}}} for v in values])
+
+
+def test_rhs_and_rk4_of_a_cabede_sweep_vs_oracle():
+    N = 100
+    base = INP.dme_notebook_input()
+    members = _members(base)
+    mech = plan.Mechanism(base, params=ENS.member_parameters(base, members))
+    pairs = [plan.member_constants(mi, mech, N) for mi in members]
+    rows = np.array([r for _, r in pairs])
+    dev = N2Device(mech, rows, N)
+    IV = np.array([plan.initial_state(nm, mech, N) for nm, _ in pairs])
+    y = dev.to_device(IV)
+    dev.rk4(y, 1e-5, 10)
+    assert not dev.status().any()
+    got = y.cpu().numpy()
+    f = dev.rhs(y).cpu().numpy()
+    for e, mi in enumerate(members):
+        pr = O.setup_n2(mi, N)
+        fv = O.make_rhs_vec(pr)
+        want = O.rk4(0.0, 10e-5, 10, pr["IV"], fv, keep=False)
+        scale = np.max(np.abs(want.reshape(7, N)), axis=1, keepdims=True)
+        assert np.max(np.abs(got[e].reshape(7, N) - want.reshape(7, N))/scale) < 1e-11, e
+        assert rowwise_err(f[e], fv(0.0, got[e]), 7) < 1e-11, e
+    assert np.max(np.abs(got[0] - got[1])) > 1e-6
+    dev.close()
+
+
+@pytest.mark.parametrize("ivp,extra", [("hip-rk4", {"dt": 2e-6}), ("hip-rk45", {}), ("hip-ros4", {})])
+def test_rmtexe_cabede_sweep_equals_single_runs(ivp, extra):
+    """One launch for the three members = three single rmtExe runs with the same parameter column bit for bit
+    (same kernel, same arithmetic), and the literal-kernel single runs within the integrator's tolerance band."""
+    def base_input():
+        mi = INP.dme_notebook_input(ivp=ivp, period=0.004)
+        mi["solver-config"].update(dict(extra, quiet=True, zNo=64, tNo=2))
+        return mi
+    mi = base_input()
+    mi["solver-config"]["ensemble"] = [{"reaction-rates": {"VARS": {"CaBeDe": v}}} for v in CABEDE]
+    sweep = rmtExe(mi)["resModel"]["ensemble"]
+    assert len(sweep) == 3
+    for e, v in enumerate(CABEDE):
+        single = base_input()
+        single["reaction-rates"]["VARS"]["CaBeDe"] = v
+        literal = rmtExe(single)["resModel"]["dataPack"]
+        single["solver-config"]["vars-as-parameters"] = ["CaBeDe"]
+        param = rmtExe(single)["resModel"]["dataPack"]
+        for k in range(2):
+            np.testing.assert_array_equal(sweep[e]["dataPack"][k]["dataYs"], param[k]["dataYs"])
+            rel = np.max(np.abs(sweep[e]["dataPack"][k]["dataYs"] - literal[k]["dataYs"])/np.abs(literal[k]["dataYs"]))
+            assert rel < (1e-12 if ivp == "hip-rk4" else 2e-6), (e, k, rel)
+    T = [m["dataPack"][1]["dataYs"][6, -1] for m in sweep]
+    assert len({round(t, 6) for t in T}) == 3                   # every member ran with its own CaBeDe
+
+
+def test_rate_constant_sweep_on_the_twelve_species_mechanism():
+    """An activity factor on the first rate of the synthetic 12-species mechanism as the swept constant (its own
+    constants are closed over by the lambdas, so the sweep adds a scalar VARS entry the wrapped rate reads)."""
+    base = INP.syn12_input(ivp="hip-rk45", period=0.01)
+    base["solver-config"].update({"quiet": True, "zNo": 48, "tNo": 1})
+    VARS, RATES = base["reaction-rates"]["VARS"], base["reaction-rates"]["RATES"]
+    VARS["act"] = 1.0
+    first = next(iter(RATES))
+
+    def scaled(inner):
+        return lambda x: x["act"]*inner(x)
+    RATES[first] = scaled(RATES[first])
+    base["solver-config"]["ensemble"] = [{"reaction-rates": {"VARS": {"act": a}}} for a in (1.0, 0.5, 2.0)]
+    sweep = rmtExe(base)["resModel"]["ensemble"]
+    members = ENS.expand_members(base, base["solver-config"]["ensemble"])
+    for e in (1, 2):
+        pr = O.setup_n2(members[e], 48)
+        want = O.rk45(O.make_rhs_vec(pr), 0.0, 0.01, pr["IV"], 1e-10, 1e-13, 1e-6)[0]
+        Y = want.reshape(13, 48)
+        conc = Y[:12]*np.max(pr["SpCoi0"])
+        ref = np.concatenate([conc/conc.sum(0), (Y[12]*pr["Tf"] + pr["Tf"]).reshape(1, -1)])
+        got = sweep[e]["dataPack"][0]["dataYs"]
+        assert np.max(np.abs(got[:, -1] - ref[:, -1])/np.abs(ref[:, -1])) < 1e-6, e
+    assert np.max(np.abs(sweep[1]["dataPack"][0]["dataYs"] - sweep[2]["dataPack"][0]["dataYs"])) > 1e-6
+
+
+def test_member_with_other_kinetics_raises_instead_of_running_the_base_mechanism():
+    mi = INP.dme_notebook_input(ivp="hip-rk4", period=1e-4)
+    mi["solver-config"].update({"quiet": True, "dt": 2e-6, "zNo": 32, "tNo": 1})
+    for override, key in (({"reactions": {"R1": "CO2 + 3H2 <=> CH3OH + H2O"}}, "'reactions'"),
+                          ({"reaction-rates": {"RATES": {"r1": lambda x: 0.0}}}, "reaction-rates.RATES"),
+                          ({"feed": {"components": {"shell": ["H2", "CO2", "H2O", "CO", "CH3OH"]}}}, "feed.components")):
+        mi["solver-config"]["ensemble"] = [{}, {}, override]
+        with pytest.raises(ValueError) as e:
+            rmtExe(mi)
+        assert "member 2" in str(e.value) and key in str(e.value)
+
+
+def test_n1_and_m2_sweeps_with_a_parameter_column():
+    """The steady-state model (one reactor per lane, rows M1_*) and the dimensional dynamic model read the same
+    user columns: every member equals its own literal single run."""
+    n1 = INP.n1_notebook_input()
+    n1["solver-config"]["ensemble"] = [{"reaction-rates": {"VARS": {"CaBeDe": v}}} for v in CABEDE]
+    packs = rmtExe(n1)["resModel"]
+    assert len(packs) == 3
+    for e in (1, 2):
+        one = INP.n1_notebook_input()
+        one["reaction-rates"]["VARS"]["CaBeDe"] = CABEDE[e]
+        single = rmtExe(one)["resModel"][0]
+        np.testing.assert_allclose(packs[e]["dataYs"], single["dataYs"], rtol=1e-7)
+    assert abs(packs[1]["dataYs"][7, -1] - packs[2]["dataYs"][7, -1]) > 0.5
+    m2 = INP.m2_dme_input(ivp="hip-rk4", period=2e-3)
+    m2["solver-config"].update({"quiet": True, "dt": 2e-6, "zNo": 64, "tNo": 1})
+    m2["solver-config"]["ensemble"] = [{"reaction-rates": {"VARS": {"CaBeDe": v}}} for v in CABEDE]
+    ens = rmtExe(m2)["resModel"]["ensemble"]
+    for e in (1, 2):
+        one = INP.m2_dme_input(ivp="hip-rk4", period=2e-3)
+        one["solver-config"].update({"quiet": True, "dt": 2e-6, "zNo": 64, "tNo": 1})
+        one["reaction-rates"]["VARS"]["CaBeDe"] = CABEDE[e]
+        single = rmtExe(one)["resModel"]["dataPack"]
+        np.testing.assert_allclose(ens[e]["dataPack"][0]["dataYs"], single[0]["dataYs"], rtol=1e-11)

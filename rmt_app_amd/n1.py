@@ -9,7 +9,7 @@ import numpy as np
 
 from . import plan
 from . import n2 as _n2
-from .settings import DEVICE_DEFAULTS, ROUND_FUN_ACCURACY, solverSetting
+from .settings import DEVICE_DEFAULTS, MODEL_SETTING, ROUND_FUN_ACCURACY, solverSetting
 
 
 def pack_profile(U, named, mech, modelId, elapsed):
@@ -20,7 +20,9 @@ def pack_profile(U, named, mech, modelId, elapsed):
     nout = Y.shape[1]
     conc_dl = Y[0:S, :]
     temp_dl = Y[S + 1, :] if not mech.iso else np.repeat(0, nout).reshape(nout)
-    conc = conc_dl*named["Cmax"]
+    # sortResult4 (solResultAnalysis.py:226-231): species i times Cif[i] when MODEL_SETTING['GaMaCoTe0'] != "MAX"
+    scale = named.get("SpCoi0_Set", named["Cmax"])
+    conc = conc_dl*(np.reshape(scale, (-1, 1)) if np.ndim(scale) else scale)
     Preal = (Y[S]*named["Pf"]).reshape((1, nout))
     mofr = conc/np.sum(conc, axis=0)
     labelList = list(mech.compList) + ["Pressure"]
@@ -63,7 +65,10 @@ def run_n1(modelInput, members_inputs=None):
         rows1 = np.ascontiguousarray(np.array([r for _, r in pairs]))
         # the handle is an N2 handle (same generated module); its N2 member rows are not used here
         dummy = np.array([plan.member_constants(mi, mech, 64)[1] for mi in inputs])
-        return pairs, rows1, _n2.device_cls()(mech, dummy, 64, block=64, npt=1, specialize=False, features=("n1",))
+        # MODEL_SETTING['GaMaCoTe0'] != "MAX": model N1 runs with per-species scaling in the reference (:2819, 3159)
+        defs = {"RMT_N1_SCALE_FIX": "1"} if MODEL_SETTING['GaMaCoTe0'] != "MAX" else None
+        return pairs, rows1, _n2.device_cls()(mech, dummy, 64, block=64, npt=1, specialize=False, features=("n1",),
+                                              defines=defs)
     pairs, rows1, dev = guarded(sync, pack_and_open)
     try:
         def launch():

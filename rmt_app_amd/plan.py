@@ -283,10 +283,25 @@ class Mechanism:
         return h.hexdigest()[:24]
 
 
+GAMACOTE_N2_ERROR = "setting an array element with a sequence."
+
+
+def check_model_setting_n2():
+    """MODEL_SETTING['GaMaCoTe0'] != "MAX" on the N2 path: the reference's modelEquationN2 then assigns the whole
+    feed-concentration ARRAY to one element (``SpCoi0_Set = SpCoi0``, pbHomoReactor.py:3901-3904, where the other
+    models write ``SpCoi0[i]``) and numpy raises ValueError on the first RHS evaluation - recorded from the reference
+    itself in tests/golden/g11_model_setting.json.  There is no N2 result under that setting to reproduce, so the
+    drop-in raises the same exception (before any device work) instead of inventing a per-species model the
+    reference never ran.  Model N1 DOES run under it (member_constants_n1, n1.py); M2 never reads the setting."""
+    if MODEL_SETTING['GaMaCoTe0'] != "MAX":
+        raise ValueError(GAMACOTE_N2_ERROR)
+
+
 def member_constants(modelInput, mech, zNo):
     """One reactor's scalars: the arithmetic of runN2's setup block (pbHomoReactor.py:3341-3466),
     returned both as a dict of named reference quantities (for parity tests and result packing)
-    and as the packed row the kernels read."""
+    and as the packed row the kernels read.  (The scaling is the "MAX" one, GaMaCoTe0[i] = (vf/zf) max(SpCoi0);
+    run_n2 refuses any other MODEL_SETTING like the reference's RHS does, see check_model_setting_n2.)"""
     mi = modelInput
     P = mi['operating-conditions']['pressure']
     T = mi['operating-conditions']['temperature']
@@ -316,9 +331,7 @@ def member_constants(modelInput, mech, zNo):
     dz = 1/(zNo - 1)                                                  # :3439 (DoLe = 1)
     Tf, Pf, vf, zf, Cpf = T, P, SuGaVe0, ReLe, GaCpMeanMix0
     Cmax = np.max(SpCoi0)
-    if MODEL_SETTING['GaMaCoTe0'] != "MAX":
-        raise NotImplementedError("only MODEL_SETTING['GaMaCoTe0'] == 'MAX' is supported")
-    GaMaCoTe0 = (vf/zf)*np.repeat(Cmax, mech.S)                       # :3462-3464
+    GaMaCoTe0 = (vf/zf)*np.repeat(Cmax, mech.S)                       # :3462-3464 ("MAX")
     GaHeCoTe0 = (GaDe0*vf*Tf*(Cpf/MiMoWe0)/zf)                        # :3466
     ergA = 150*GaMiVi*SuGaVe0/(PaDi**2)                               # :3970-3973 with v == vf
     ergB = ((1 - BeVoFr)**2)/(BeVoFr**3)
@@ -429,7 +442,10 @@ MEMBER1_FIELDS = {
 def member_constants_n1(modelInput, mech):
     """Packed constants of the steady-state model N1: the setup block of runN1
     (pbHomoReactor.py:2694-2900) - identical to runN2's apart from vf = VoFlRa0/CrSeAr - and the
-    h-independent factors of modelEquationN1 (:3017-3314); layout M1_* in csrc/kernels/22_node_n1.inc."""
+    h-independent factors of modelEquationN1 (:3017-3314); layout M1_* in csrc/kernels/22_node_n1.inc.
+    The row is the same for both values of MODEL_SETTING['GaMaCoTe0']: under the per-species scaling the kernel
+    (RMT_N1_SCALE_FIX, set by n1.run_n1) derives scale_i = CMAX*CIN_i and 1/GaMaCoTe0[i] = INV_MACOTE/CIN_i from it;
+    the named dict carries "SpCoi0_Set" / "GaMaCoTe0" as the reference would have them (:2819-2821, 3159-3160)."""
     nm, _ = member_constants(modelInput, mech, 2)
     mi = modelInput
     ReSpec = mi['reactor']
@@ -455,7 +471,9 @@ def member_constants_n1(modelInput, mech):
     row[F["TM"]] = nm["Tm"]
     row[F["GADE0"]] = nm["GaDe0"]
     row[F["CIN"]:F["CIN"] + mech.S] = nm["SpCoi0"]/nm["Cmax"]
-    nm = dict(nm, vf=vf)
+    fix = MODEL_SETTING['GaMaCoTe0'] != "MAX"
+    nm = dict(nm, vf=vf, SpCoi0_Set=np.array(nm["SpCoi0"], dtype=float) if fix else nm["Cmax"],
+              GaMaCoTe0=(vf/zf)*(np.array(nm["SpCoi0"], dtype=float) if fix else np.repeat(nm["Cmax"], mech.S)))
     return nm, row
 
 

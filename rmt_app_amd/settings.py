@@ -18,7 +18,11 @@ solverSetting = {
     "T1": {"ode-solver": {"PreCorr3": {"n": 100}}},
 }
 
-MODEL_SETTING = {"GaMaCoTe0": "MAX"}
+# (only "GaMaCoTe0" is read on the homogeneous paths built here: N2 raises under any value but "MAX" exactly like the
+# reference's own RHS does, N1 switches to per-species scaling, M2 ignores it - golden G11; the other keys belong to
+# the heterogeneous models)
+MODEL_SETTING = {"g": "FIX", "MaTrCo": "FIX", "HeTrCo": "FIX", "GaDii": "FIX", "GaThCoi": "FIX", "GaVii": "FIX",
+                 "GaMaCoTe0": "MAX"}
 PROCESS_SETTING = {"ISO-THER": "iso-thermal", "NON-ISO-THER": "non-iso-thermal"}
 
 # defaults of the device integrators (not in the reference: it delegates to scipy's defaults)

@@ -82,8 +82,10 @@ def test_cabi_error_paths_under_asan():
     assert r.returncode == 0, r.stderr[-2000:]
     rt = subprocess.run(["make", "-s", "-C", csrc, "asan-rt"], capture_output=True, text=True).stdout.strip()
     assert os.path.exists(rt), rt
+    # the child never sees a GPU, whatever box this runs on: sanitizer runs stay on the CPU build
     env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1",
-               RMT_N2_LIBRARY=os.path.join(ROOT, "rmt_app_amd", "librmt_n2_asan.so"))
+               RMT_N2_LIBRARY=os.path.join(ROOT, "rmt_app_amd", "librmt_n2_asan.so"),
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "asan_cabi_paths.py")],
                        capture_output=True, text=True, env=env, timeout=600)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
@@ -551,3 +553,110 @@ def test_default_compile_options_and_caller_override():
     again, _ = hipbind.compile_source(src, extra_opts="-mllvm -disable-machine-licm")
     assert blob[:4] == b"\x7fELF" and again[:4] == b"\x7fELF"
     assert len(hipbind.hiprtc_tag()) == 8
+
+
+# ----------------------------------------------------------------------------- MODEL_SETTING['GaMaCoTe0'] (golden G11)
+@pytest.fixture
+def gamacote_fix():
+    from rmt_app_amd import MODEL_SETTING
+    old = MODEL_SETTING["GaMaCoTe0"]
+    MODEL_SETTING["GaMaCoTe0"] = "FIX"
+    try:
+        yield
+    finally:
+        MODEL_SETTING["GaMaCoTe0"] = old
+
+
+def test_model_setting_n2_raises_like_the_reference(gamacote_fix, capsys):
+    """Under MODEL_SETTING['GaMaCoTe0'] != "MAX" the reference's N2 run ends in numpy's ValueError (the RHS assigns
+    the feed-concentration array to one element, pbHomoReactor.py:3901-3904) - recorded from the reference in golden
+    G11; rmtExe here raises the same exception (printing it first, PyREMOT/rmt.py:78-80), and M2 is unaffected."""
+    from rmt_app_amd import rmtExe
+    g = json.load(open(os.path.join(G, "g11_model_setting.json")))
+    assert g["N2"]["raises"] == "ValueError" and g["N1"]["raises"] is None and g["M2"]["raises"] is None
+    with pytest.raises(ValueError) as e:
+        rmtExe(INP.dme_notebook_input())
+    assert str(e.value) == g["N2"]["message"]
+    assert g["N2"]["message"] in capsys.readouterr().out
+    mech = plan.Mechanism(INP.m2_dme_input())
+    plan.member_constants_m2(INP.m2_dme_input(), mech, 20)            # no setting involved
+
+
+def test_model_setting_n1_per_species_scaling_vs_reference(gamacote_fix, template):
+    """Model N1 under the per-species scaling: the generated node function (RMT_N1_SCALE_FIX) and the oracle against
+    the reference's modelEquationN1 probes recorded under that setting (golden G11), and the analytic Jacobian
+    against forward differences."""
+    g = np.load(os.path.join(G, "g11_n1_fix.npz"))
+    mi = INP.n1_notebook_input()
+    mech = plan.Mechanism(mi)
+    nm, row = plan.member_constants_n1(mi, mech)
+    pr = O.setup_n1(mi, gamacote="FIX")
+    assert relerr(nm["GaMaCoTe0"], pr["GaMaCoTe0"]) < 1e-14 and np.ndim(nm["SpCoi0_Set"]) == 1
+    Y, F = g["rhs_y"], g["rhs_f"]
+    emu = HostEmu(mech.source(template, defines={"RMT_N1_SCALE_FIX": "1", "RMT_WITH_N1": "1"}), tag="dme_n1fix", openmp=False)
+    out, flags = emu.n1_rhs(Y, np.tile(row, (len(Y), 1)))
+    assert not flags.any()
+    for k in range(len(Y)):
+        assert relerr(O.n1_rhs(0.37, Y[k], pr), F[k]) < 1e-12, k
+        assert relerr(out[k], F[k]) < (1e-11 if k < 2 else 1e-7), (k, out[k], F[k])
+    # ... and it is a different function from the "MAX" one
+    g6 = np.load(os.path.join(G, "g6_n1.npz"))
+    assert relerr(F[0], g6["rhs_f"][0]) > 0.1
+    jan, jfd, fan, fref = emu.n1_jac(Y, np.tile(row, (len(Y), 1)))
+    assert np.max(np.abs(fan - fref)/np.maximum(np.abs(fref), 1e-300)) < 1e-12
+    for k in range(len(Y)):
+        scale = np.max(np.abs(jfd[k]), axis=1, keepdims=True)
+        assert np.max(np.abs(jan[k] - jfd[k])/scale) < 1e-4, k
+    # the reference's own default-tolerance profile under the setting vs the oracle run the same way
+    ref = O.run_n1(mi, zNo=100, method="LSODA", gamacote="FIX")
+    assert np.max(np.abs(ref["dataYs"] - g["dataYs"])/np.abs(g["dataYs"])) < 5e-3
+
+
+# ----------------------------------------------------------------------------- ensemble result packing
+@pytest.mark.parametrize("process_type", ["non-iso-thermal", "iso-thermal"])
+def test_batched_packing_equals_per_member_packing(process_type):
+    """pack_intervals (all members of a sweep at once) against pack_interval (sortResult5 per member): every key,
+    shape, dtype and bit."""
+    from rmt_app_amd.ensemble import expand_members
+    from rmt_app_amd.n2 import pack_intervals
+    base = INP.dme_notebook_input(process_type=process_type)
+    members = expand_members(base, {"temperature": np.linspace(503, 543, 9), "pressure": [3e6, 5e6]})
+    mech = plan.Mechanism(base)
+    named = [plan.member_constants(m, mech, 40)[0] for m in members]
+    Y = np.random.default_rng(5).random((len(members), mech.V*40))
+    one = [pack_interval(Y[e], named[e], mech, 40, 0.1, "N2") for e in range(len(members))]
+    for a, b in zip(one, pack_intervals(Y, named, mech, 40, 0.1, "N2")):
+        assert list(a) == list(b)
+        for k in a:
+            if isinstance(a[k], np.ndarray):
+                assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k], k
+
+
+def test_ensemble_output_outlet_keeps_only_the_last_node():
+    """solver-config "ensemble-output": "outlet" (host-emulation stand-in for the device): every dataPack entry holds
+    the outlet column of the full-profile run, same schema, one axial point."""
+    import emu_device
+    from rmt_app_amd import n2, rmtExe
+
+    def run(**extra):
+        mi = INP.dme_notebook_input(ivp="hip-rk4", period=2e-4)
+        mi["solver-config"].update(dict({"quiet": True, "dt": 2e-6, "zNo": 24, "tNo": 2,
+                                         "ensemble": {"temperature": [513.0, 533.0], "pressure": [4e6, 5e6]}}, **extra))
+        real, n2.N2Device = n2.N2Device, emu_device.EmuDevice
+        try:
+            return rmtExe(mi)["resModel"]["ensemble"]
+        finally:
+            n2.N2Device = real
+    full, out = run(), run(**{"ensemble-output": "outlet"})
+    assert len(full) == len(out) == 4
+    for f, o in zip(full, out):
+        for k in range(2):
+            a, b = f["dataPack"][k], o["dataPack"][k]
+            assert list(a) == list(b) and b["dataYs"].shape == (7, 1) and list(b["dataXs"]) == [1.0]
+            for key in ("dataYs", "dataYCons1", "dataYCons2", "dataYTemp2"):
+                np.testing.assert_array_equal(b[key][:, 0], a[key][:, -1])
+            assert b["dataYTemp1"][0] == a["dataYTemp1"][-1] and b["dataTime"] == a["dataTime"]
+    with pytest.raises(ValueError):
+        run(**{"ensemble-output": "everything"})

@@ -5,7 +5,7 @@ Runs only in the build container, where /root/reference exists:
 
     PYTHONPATH=/root/reference MPLBACKEND=Agg python3 tools/make_golden.py <what> [...]
 
-<what> in: setup rhs rk4 tight default n1 helpers all   (see SURVEY.md section 8(c), G1..G7).
+<what> in: setup rhs rk4 tight=<case> default=<case> multistep n1 helpers plot m2 m2run setting  (see SURVEY.md section 8(c), G1..G7).
 The reference never travels to the GPU box; only the small .npz/.json files written here do.
 Inputs come from tests/inputs.py (this repo's restatement of the reference's test inputs).
 """
@@ -533,6 +533,61 @@ def g_plot():
     print("G10 written")
 
 
+def g_model_setting():
+    """G11: what the reference does when MODEL_SETTING['GaMaCoTe0'] is not "MAX" (the per-species scaling branch of
+    pbHomoReactor.py:3461-3463 / :3901-3904 / :3159-3160 and solResultAnalysis.py:285-288).  Recorded, not assumed:
+    rmtExe is run end to end for N2 and N1 (zNo = 20) with the setting mutated, and for M2 (which never reads it);
+    the outcome - exception type and message, or success - is the fixture the device build is held to."""
+    import PyREMOT.docs.modelSetting as MS
+    out = {"setting": "FIX", "reference": "PyREMOT %s" % getattr(PyREMOT, "__version__", "1.0.17")}
+    cases = {"N2": (INP.dme_notebook_input(period=0.01), "N2"), "N1": (INP.n1_notebook_input(), "N1"),
+             "M2": (INP.m2_dme_input(period=0.01), "S2")}
+    old = MS.MODEL_SETTING["GaMaCoTe0"]
+    MS.MODEL_SETTING["GaMaCoTe0"] = "FIX"            # the one dict object every module imported
+    try:
+        for name, (mi, key) in cases.items():
+            try:
+                with mesh(20, 2, key) if key != "N1" else mesh(20, None, key), quiet():
+                    rmtExe(mi)
+                out[name] = {"raises": None}
+            except Exception as e:                   # noqa: BLE001 - the outcome IS the fixture
+                out[name] = {"raises": type(e).__name__, "message": str(e)}
+        # N1 runs under "FIX" (per-species scale SpCoi0[i], GaMaCoTe0[i] = (vf/zf) SpCoi0[i], while the initial
+        # values stay SpCoi0[i]/max(SpCoi0), pbHomoReactor.py:2819-2834, 3159-3162): record its profile and RHS probes
+        mi = INP.n1_notebook_input()
+        with quiet():
+            d = rmtExe(mi)["resModel"][0]
+        prof = {k: np.array(d[k], dtype=float) for k in
+                ("dataYs", "dataYCons1", "dataYCons2", "dataYTemp1", "dataYTemp2", "dataXs")}
+        box = {}
+
+        def fake(fun, t_span, y0, method=None, t_eval=None, args=None, **kw):
+            box["IV"] = np.array(y0, float)
+            box["params"] = args[0]
+            raise _Captured()
+        PBH.solve_ivp = fake
+        try:
+            with quiet():
+                try:
+                    rmtExe(mi)
+                except _Captured:
+                    pass
+        finally:
+            PBH.solve_ivp = REAL_SOLVE_IVP
+        ys = [box["IV"], d["dataYCons1"][:, 50].tolist() + [d["dataYs"][6, 50]/5e6, d["dataYTemp1"][50]],
+              d["dataYCons1"][:, 100].tolist() + [d["dataYs"][6, 100]/5e6, d["dataYTemp1"][100]]]
+        ys = np.array([np.array(y, float) for y in ys])
+        with quiet():
+            prof["rhs_f"] = np.array([PB.modelEquationN1(0.37, y, box["params"]) for y in ys])
+        prof["rhs_y"] = ys
+        np.savez_compressed(os.path.join(GOLD, "g11_n1_fix.npz"), **prof)
+    finally:
+        MS.MODEL_SETTING["GaMaCoTe0"] = old
+    with open(os.path.join(GOLD, "g11_model_setting.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(out)
+
+
 def main(argv):
     os.makedirs(GOLD, exist_ok=True)
     for what in argv:
@@ -554,6 +609,8 @@ def main(argv):
             g_helpers()
         elif what == "plot":
             g_plot()
+        elif what == "setting":
+            g_model_setting()
         elif what == "m2":
             g_m2()
         elif what.startswith("m2run"):

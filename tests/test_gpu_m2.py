@@ -235,3 +235,73 @@ def test_m2_chained_stiff_stepper_matches_one_workgroup(N, E):
     assert np.array_equal(stats["chain"]["accepted"], stats["mem"]["accepted"])
     for e in range(E):
         assert rowwise_err(out["chain"][e], out["mem"][e], mech.V) < 1e-8
+
+
+# ----------------------------------------------------------------------------- chained steppers vs the oracle (not vs each other)
+def test_m2_chained_rk45_vs_oracle_controller():
+    """Model M2 under rmt_n2_rk45_chain at a mesh that forces 5 chunks (N = 300, 64-node chunks, ragged tail), two
+    reactors with their own step sequences: the accept / reject history of the oracle's Dormand-Prince controller
+    driving the ORACLE's M2 right-hand side (itself pinned to the reference's modelEquationM2, golden G9), end state
+    within 50 rtol."""
+    N, t1, rtol, atol, h0 = 300, 6e-3, 1e-7, 1e-10, 1e-6
+    base = INP.m2_dme_input()
+    mech = plan.Mechanism(base)
+    mis, rows, ivs = [], [], []
+    for dT in (0.0, 12.0):
+        mi = INP.m2_dme_input()
+        mi["operating-conditions"]["temperature"] = base["operating-conditions"]["temperature"] + dT
+        nm, row = plan.member_constants_m2(mi, mech, N)
+        mis.append(mi), rows.append(row), ivs.append(plan.initial_state_m2(nm, mech, N))
+    dev = N2Device(mech, np.array(rows), N, block=64, npt=1, defines={"RMT_RK45_LDS": "2"})
+    dev.set_mode("chain")
+    y = dev.to_device(np.array(ivs))
+    dev.rk45(y, 0.0, t1, rtol, atol, h0, 10**7)
+    assert not dev.status().any()
+    st, got = dev.rk45_stats(), y.cpu().numpy()
+    for e, mi in enumerate(mis):
+        pr = M2O.setup_m2(mi, N)
+        want, ost = O.rk45(M2O.make_rhs_vec(pr), 0.0, t1, pr["IV"], rtol, atol, h0)
+        assert st["t_end"][e] == t1
+        assert abs(int(st["accepted"][e]) - ost["accepted"]) <= max(2, 0.02*ost["accepted"]), (e, st, ost)
+        assert abs(int(st["rejected"][e]) - ost["rejected"]) <= max(3, 0.05*ost["accepted"]), (e, st, ost)
+        assert rowwise_err(got[e], want, mech.V) < 50*rtol, e
+    dev.close()
+
+
+_M2_TIGHT = {}
+
+
+def _m2_tight_reference(N, t1):
+    """SciPy LSODA at rtol 1e-11 on the oracle's M2 right-hand side (computed once per session: ~20 s of CPU)."""
+    from scipy.integrate import solve_ivp
+    if (N, t1) not in _M2_TIGHT:
+        pr = M2O.setup_m2(INP.m2_dme_input(), N)
+        sol = solve_ivp(M2O.make_rhs_vec(pr), (0, t1), pr["IV"], method="LSODA", rtol=1e-11, atol=1e-14)
+        assert sol.success
+        _M2_TIGHT[(N, t1)] = (pr, sol.y[:, -1])
+    return _M2_TIGHT[(N, t1)]
+
+
+@pytest.mark.parametrize("stepper,tol", [("rk4", 1e-8), ("rk45", 2e-7), ("ros4", 1e-6)])
+def test_m2_chained_steppers_vs_scipy_on_the_oracle_rhs(stepper, tol):
+    """The three chained M2 steppers (3 chunks of 64 nodes) against SciPy's LSODA at rtol 1e-11 integrating the oracle's
+    M2 right-hand side over the first 10 ms: whole state and outlet mole fractions / temperature."""
+    from rmt_app_amd.settings import DEVICE_DEFAULTS as D
+    N, t1 = 192, 0.01
+    kw = {"features": ("ros4",)} if stepper == "ros4" else {"defines": {"RMT_RK45_LDS": "2"}}
+    mi, mech, nm, dev = make_device(N, block=64, npt=1, **kw)
+    dev.set_mode("chain")
+    y = dev.to_device(plan.initial_state_m2(nm, mech, N))
+    if stepper == "rk4":
+        dev.rk4(y, 2e-6, 5000)
+    elif stepper == "rk45":
+        dev.rk45(y, 0.0, t1, 1e-9, 1e-12, 1e-6, 10**7)
+    else:
+        dev.ros4(y, 0.0, t1, 1e-8, 1e-11, D["ros4-h0"], 10**7)
+    assert not dev.status().any()
+    got = y.cpu().numpy()[0]
+    dev.close()
+    pr, want = _m2_tight_reference(N, t1)
+    assert rowwise_err(got, want, mech.V) < tol
+    a, b = M2O.pack_interval(got, pr)["dataYs"][:, -1], M2O.pack_interval(want, pr)["dataYs"][:, -1]
+    assert np.max(np.abs(a - b)/np.abs(b)) < tol

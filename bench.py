@@ -178,6 +178,7 @@ def single_reactor_4096(mech, inputs):
         torch.cuda.synchronize()
         walls[mode] = time.perf_counter() - t0
         ok = ok and not devr.status().any()
+        geo = devr.last_geometry()
     wall = walls["auto"]
     st = devr.rk45_stats()
     devr.close()
@@ -190,7 +191,8 @@ def single_reactor_4096(mech, inputs):
     ref = reference_cpu_rate(1024)
     return {"nodes": N, "rk4_node_steps_per_s": N*2000/(ms*1e-3), "rk4_us_per_step": ms/2.0,
             "ros4_whole_0.5s_job_wall_s": round(wall, 4), "ros4_one_workgroup_wall_s": round(walls["mem"], 4),
-            "ros4_kernel": "rmt_n2_ros4_chain, 16 chunks of 256 nodes", "ros4_steps": int(st["accepted"][0] + st["rejected"][0]),
+            "ros4_kernel": "rmt_n2_ros4_%s, %d chunks x %d teams (chosen by the library)" % (
+                "chain" if geo[0] > 1 else "mem", geo[0], geo[1]), "ros4_steps": int(st["accepted"][0] + st["rejected"][0]),
             "flags_ok": bool(ok), "cpu_port_1core_node_steps_per_s": cpu,
             "reference_python_rk4_equiv_node_steps_per_s": ref["value"] if ref else None}
 
@@ -254,6 +256,95 @@ def time_to_solution(mech, rows, IV, n_nodes, t_end=0.5):
             "rtol": D["ros4-rtol"], "atol": D["ros4-atol"]}
 
 
+MESH_SWEEP = ((256, 4096), (64, 16384), (1, 16384))       # BASELINE configs[2]: (reactors, nodes)
+STREAM_E, STREAM_N = 16384, 1024                           # rhs_stream: 16384 x 1024 x 7 fp64 = 0.94 GB in + 0.94 GB out
+
+
+def mesh_sweep(mech, inputs):
+    """BASELINE configs[2] ("same dynamic model at 4096 and 16384 axial nodes - HBM-roofline sweep"): RK4 with the
+    reactors cut into chunks on several CUs (rmt_n2_rk4_chain) for 256 x 4096, 64 x 16384 and ONE 16384-node
+    reactor; node-steps/s, the contract's 128 B/node-step figure against 8 TB/s and the fp64 VALU fraction."""
+    from rmt_app_amd import isa, plan
+    from rmt_app_amd.n2 import N2Device
+    out = {}
+    for E, N in MESH_SWEEP:
+        nm, row = plan.member_constants(inputs[0], mech, N)
+        dev = N2Device(mech, np.tile(row, (E, 1)), N)
+        y = dev.to_device(np.tile(plan.initial_state(nm, mech, N), (E, 1)))
+        steps = 1000 if E > 1 else 2000
+        dev.rk4(y, DT, steps//10)
+        dev.rk4(y, DT, steps)
+        ms = dev.last_kernel_ms()
+        ok = not dev.status().any()
+        W = dev.block*dev.npt
+        kname = "rmt_n2_rk4_%s" % ("reg" if N <= W else "chain")
+        loop = isa.kernel_stats(bytes(dev._code.raw), kname)
+        loop = loop.get("step_loop") or loop["whole"]
+        rate = E*N*steps/(ms*1e-3)
+        out["%dx%d" % (E, N)] = {
+            "node_steps_per_s": rate, "kernel_ms": ms, "rk4_steps": steps,
+            "kernel": "%s block=%d npt=%d chunks=%d" % (kname, dev.block, dev.npt, -(-N//W)),
+            "hbm_contract_frac": rate*2*(mech.S + 2)*8/1e9/HBM_PEAK_GBS,
+            "valu_fp64_frac": rate*loop["valu_f64"]/float(dev.npt)/(FP64_PEAK_TOPS*1e12), "flags_ok": bool(ok)}
+        dev.close()
+    return out
+
+
+def rhs_stream(mech, inputs):
+    """The one regime of this path where the HBM roofline is the real bound: the bare RHS kernel (rmt_n2_rhs: y in,
+    dy/dt out) on a state far beyond the 256 MB Infinity Cache - 16384 reactors x 1024 nodes, 0.94 GB read + 0.94 GB
+    written per launch.  ALGORITHMIC bytes (2 V 8 B per node) / HIP-event kernel time against 8 TB/s; the PMC
+    FETCH_SIZE / WRITE_SIZE of the same launch are in profiles/ (tools/record_traffic.py)."""
+    import torch
+    from rmt_app_amd import plan
+    from rmt_app_amd.n2 import N2Device
+    E, N = STREAM_E, STREAM_N
+    nm, row = plan.member_constants(inputs[0], mech, N)
+    dev = N2Device(mech, np.tile(row, (E, 1)), N, block=STREAM_BLOCK, npt=1, specialize=False)
+    y = dev.to_device(np.tile(plan.initial_state(nm, mech, N), (E, 1)))
+    out = dev.rhs(y)
+    ms = []
+    for _ in range(10):
+        out = dev.rhs(y)
+        ms.append(dev.last_kernel_ms())
+    ok = not dev.status().any()
+    t = float(np.median(ms))
+    by = 2*mech.V*8*E*N
+    dev.close()
+    del y, out
+    torch.cuda.empty_cache()
+    return {"reactors": E, "nodes": N, "state_GB_in_plus_out": by/1e9, "kernel": "rmt_n2_rhs block=%d" % STREAM_BLOCK,
+            "kernel_ms": t, "node_rhs_per_s": E*N/(t*1e-3), "achieved_GBs": by/(t*1e-3)/1e9, "peak_GBs": HBM_PEAK_GBS,
+            "frac": by/(t*1e-3)/1e9/HBM_PEAK_GBS, "achieved_is": "algorithmic bytes (2 V 8 B per node) / kernel time",
+            "flags_ok": bool(ok)}
+
+
+STREAM_BLOCK = 256
+
+
+def rmtexe_ensemble_wall(n_nodes, members=MEMBERS_PER_GPU):
+    """What a user of the sweep sees: rmtExe on this rank's 256-member inlet-T / pressure sweep, whole 0.5 s transient,
+    5 output times, stiff stepper - wall time including the member packing, the launches, the device-to-host copies
+    of every output time and the dataPack construction; once with every member's full profile returned and once with
+    solver-config "ensemble-output": "outlet"."""
+    import inputs as INP
+    from rmt_app_amd import rmtExe
+    out = {"members": members, "nodes": n_nodes, "output_times": 5, "integrator": "hip-ros4"}
+    nT = members//32
+    for mode in ("profile", "outlet"):
+        mi = INP.dme_notebook_input(ivp="hip-ros4")
+        mi["solver-config"].update({"quiet": True, "zNo": n_nodes, "tNo": 5, "ensemble-output": mode,
+                                    "ensemble": {"temperature": list(np.linspace(503.0, 543.0, 64)[:nT]),
+                                                 "pressure": list(np.linspace(3.0e6, 7.0e6, 32))}})
+        t0 = time.perf_counter()
+        res = rmtExe(mi)["resModel"]
+        out["%s_wall_s" % mode] = round(time.perf_counter() - t0, 4)
+        assert len(res["ensemble"]) == members and len(res["ensemble"][-1]["dataPack"]) == 5
+    out["outlet_T_first_last_member_K"] = [float(res["ensemble"][0]["dataPack"][-1]["dataYs"][6, -1]),
+                                           float(res["ensemble"][-1]["dataPack"][-1]["dataYs"][6, -1])]
+    return out
+
+
 def prebuild(members=MEMBERS_PER_GPU, n_nodes=N_NODES):
     """Cross-compile (hipRTC; no GPU) every code object the default `python bench.py` run loads, into the in-tree
     cache that travels with the repository - called by __graft_entry__.build(), so the bench on a fresh GPU box
@@ -288,8 +379,14 @@ def prebuild(members=MEMBERS_PER_GPU, n_nodes=N_NODES):
     _, rs = plan.member_constants(INP.syn12_input(), ms, 1024)
     block, npt, defs = rk45_geometry(ms.V, 1024, E=256)
     keys.append(precompile(ms, np.tile(rs, (256, 1)), 1024, block=block, npt=npt, defines=defs))
-    # time_to_solution
+    # time_to_solution / rmtexe_ensemble_wall
     keys.append(precompile(mech, rows, n_nodes, block=256, npt=1, features=("ros4",)))
+    # mesh_sweep, rhs_stream
+    for E, N in MESH_SWEEP:
+        _, r = plan.member_constants(inputs[0], mech, N)
+        keys.append(precompile(mech, np.tile(r, (E, 1)), N))
+    _, r = plan.member_constants(inputs[0], mech, STREAM_N)
+    keys.append(precompile(mech, np.tile(r, (2, 1)), STREAM_N, block=STREAM_BLOCK, npt=1, specialize=False))
     return keys
 
 
@@ -442,7 +539,7 @@ def main():
             # bandwidth headroom: the limiter is fp64 VALU issue, priced in `valu_fp64`.
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved/HBM_PEAK_GBS, "achieved_is": "algorithmic bytes / kernel time",
-                         "limiter": "valu_fp64",
+                         "limiter": "valu_fp64", "limiter_frac": valu_rate/(FP64_PEAK_TOPS*1e12),
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE+WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "measured_hbm_GBs": (traffic/1e9)/(kernel_ms/1e3) if traffic else None,
@@ -466,9 +563,12 @@ def main():
             line["cpu_baseline"]["reference_python"] = reference_cpu_rate(n_nodes)
             line["accuracy"] = accuracy_vs_scipy_reference()
             line["single_reactor_4096"] = single_reactor_4096(mech, inputs)
+            line["mesh_sweep"] = mesh_sweep(mech, inputs)
+            line["rhs_stream"] = rhs_stream(mech, inputs)
             line["adaptive_rk45"] = adaptive_rk45(mech, rows, IV, n_nodes)
             line["time_to_solution"] = time_to_solution(mech, rows, IV, n_nodes)
             line["time_to_solution"]["rk4_equivalent_wall_s"] = round(250000*tmax/(args.steps*RK4_PER_STEP), 3)
+            line["rmtexe_ensemble_wall_s"] = rmtexe_ensemble_wall(n_nodes, E)
         print(json.dumps(line))
     if distributed:
         dist.barrier()

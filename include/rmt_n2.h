@@ -160,6 +160,9 @@ int rmt_n2_status(rmt_n2_handle* h, uint32_t* flags_host);
  * into chunks on several CUs, the teams working through the ensemble in rounds, is estimated to be faster),
  * 1 = on-chip single workgroup, 2 = one workgroup per reactor with the state in memory, 3 = chained workgroups */
 int rmt_n2_set_mode(rmt_n2_handle* h, int mode);
+/* how the last rk4 / rk45 / ros4 launch was laid out: workgroups (chunks) per reactor - 1 = one workgroup per reactor -
+ * and the number of teams that worked through the ensemble (= E when every reactor had its own workgroup) */
+int rmt_n2_last_geometry(rmt_n2_handle* h, int* chunks, int* teams);
 /* timing of the last rk4/rk45/rhs launch in ms (HIP events on the handle's stream; synchronises) */
 int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms);
 

@@ -60,6 +60,7 @@ struct rmt_n2_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int last_chunks = 1, last_teams = 0;     // geometry of the last stepper launch (rmt_n2_last_geometry)
 };
 
 // Every entry point runs on the device the handle was created on: workspace allocations, event
@@ -296,12 +297,21 @@ static int ensure_rings(rmt_n2_handle* h, int T, int C, unsigned long long** dec
     return 0;
 }
 
-static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1) {
+static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1, int chunks = 1, int teams = 0) {
+    h->last_chunks = chunks;
+    h->last_teams = teams > 0 ? teams : h->E;
     HIP_OK(hipEventRecord(h->ev0, h->stream));
     HIP_OK(hipModuleLaunchKernel(f, (unsigned)(grid > 0 ? grid : h->E), 1, 1, (unsigned)h->block, 1, 1, 0,
                                  h->stream, args, nullptr));
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    return 0;
+}
+
+extern "C" int rmt_n2_last_geometry(rmt_n2_handle* h, int* chunks, int* teams) {
+    if (!h || !chunks || !teams) return fail("null argument");
+    *chunks = h->last_chunks;
+    *teams = h->last_teams;
     return 0;
 }
 
@@ -365,7 +375,7 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
                         (void*)&dt, (void*)&ns, (void*)&h->d_sync, (void*)&h->d_slots, (void*)&h->d_flags,
                         (void*)&h->d_rings, (void*)&abort_words};
-        return launch(h, h->f_rk4_chain, args, T * C);
+        return launch(h, h->f_rk4_chain, args, T * C, C, T);
     }
     if (ensure_work(h, 3)) return 1;
     void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,
@@ -422,7 +432,7 @@ extern "C" int rmt_n2_rk45(rmt_n2_handle* h, void* y, double t0, double t1, doub
             void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T, (void*)&t0,
                             (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms, (void*)&stats,
                             (void*)&h->d_flags, (void*)&h->d_rings, (void*)&decision, (void*)&abort_words};
-            return launch(h, h->f_rk45_chain, args, T * C);
+            return launch(h, h->f_rk45_chain, args, T * C, C, T);
         }
     }
     if (!h->f_rk45_mem) return fail("code object has no rk45 kernel");
@@ -492,7 +502,7 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
         void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
                         (void*)&W, (void*)&t0, (void*)&t1, (void*)&rtol, (void*)&atol, (void*)&h0, (void*)&ms,
                         (void*)&stats, (void*)&h->d_flags, (void*)&h->d_rings, (void*)&decision, (void*)&abort_words};
-        return launch(h, h->f_ros4_chain, args, T * C);
+        return launch(h, h->f_ros4_chain, args, T * C, C, T);
     }
     // 7 vector arrays + the VxV inverse per node (= V more "vector arrays")
     if (ensure_work(h, 8 + (size_t)h->V)) return 1;   // 7 stage arrays + VxV inverses + upwind coupling (model M2)

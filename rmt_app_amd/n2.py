@@ -291,6 +291,12 @@ class N2Device:
         hipbind.check(hipbind.lib().rmt_n2_status(self.h, flags.ctypes.data_as(C.POINTER(C.c_uint32))))
         return flags
 
+    def last_geometry(self):
+        """(workgroups per reactor, teams) of the last rk4 / rk45 / ros4 launch - what the library's auto mode chose."""
+        c, t = C.c_int(), C.c_int()
+        hipbind.check(hipbind.lib().rmt_n2_last_geometry(self.h, C.byref(c), C.byref(t)))
+        return c.value, t.value
+
     def last_kernel_ms(self):
         ms = C.c_float()
         hipbind.check(hipbind.lib().rmt_n2_last_kernel_ms(self.h, C.byref(ms)))

@@ -76,5 +76,7 @@ assert L.rmt_n2_set_stream(null, null) != 0
 assert L.rmt_n2_set_mode(null, 0) != 0
 ms = C.c_float()
 assert L.rmt_n2_last_kernel_ms(null, C.byref(ms)) != 0
+ci = C.c_int()
+assert L.rmt_n2_last_geometry(null, C.byref(ci), C.byref(ci)) != 0
 L.rmt_n2_destroy(null)
 print("ASAN_CABI_OK")

@@ -737,15 +737,12 @@ class Lowered:
         return Gradient(g2, [new[o].i for o in self.outputs], partial, self.S, n_primal, wrt)
 
     # ---- HIP C++ emission
-    def _emit_body(self, nocheck_from=None):
-        """Straight-line code for every live node -> (lines, {node: C expression}).  Nodes with an id
-        >= nocheck_from (the derivative part of a gradient DAG) are printed without the
-        Python-exception tests: they are not expressions the reference evaluates."""
+    def _emitter(self, nocheck_from=None):
+        """-> emit(i, name, declare=True, nocheck=False): lines of HIP C++ for live node i (appending its C expression
+        to ``name``).  ``declare`` False prints an assignment to an already declared ``v<i>`` instead of a
+        ``const real`` definition (nodes evaluated inside a branch and used after it)."""
         g = self.g
-        lines = []
-        name = {}
         seen_checks = set()
-
         table = getattr(self, "_const_table", None)
 
         def lit(v):
@@ -762,15 +759,16 @@ class Lowered:
                 return "real(RMT_KTAB[%d])" % table[v]
             return "real(%s)" % repr(v)
 
-        for i in sorted(self.live):
+        def emit(i, name, declare=True, nocheck=False):
+            lines = []
             op, a, b = g.nodes[i]
             if op == "const":
                 name[i] = lit(g.cval(i))
-                continue
+                return lines
             if op == "in":
                 name[i] = a if a in ("T", "P") else ("x[%s]" % a[1:] if a[0] == "x" else (
                     "U[%s]" % a[1:] if a[0] == "u" else "C[%s]" % a[1:]))
-                continue
+                return lines
             v = "v%d" % i
             A = name[a]
             B = name[b] if (b is not None and op != "powi") else None
@@ -849,17 +847,128 @@ class Lowered:
                 raise LoweringError("no device emission for op %r" % op)
             for p in pre:
                 if p.startswith("RMT_CHECK"):
-                    if p in seen_checks or (nocheck_from is not None and i >= nocheck_from):
+                    if nocheck or p in seen_checks or (nocheck_from is not None and i >= nocheck_from):
                         continue
-                    seen_checks.add(p)
+                    if declare:               # (a check printed inside a branch does not cover the code after it)
+                        seen_checks.add(p)
                 lines.append("    " + p)
-            lines.append("    const real %s = %s;" % (v, e))
+            lines.append(("    const real %s = %s;" if declare else "    %s = %s;") % (v, e))
             name[i] = v
+            return lines
+        return emit
+
+    def _emit_body(self, nocheck_from=None):
+        """Straight-line code for every live node -> (lines, {node: C expression}).  Nodes with an id
+        >= nocheck_from (the derivative part of a gradient DAG) are printed without the
+        Python-exception tests: they are not expressions the reference evaluates."""
+        emit = self._emitter(nocheck_from)
+        lines, name = [], {}
+        for i in sorted(self.live):
+            lines.extend(emit(i, name))
         return lines, name
 
-    def emit(self, fname="rmt_kinetics", const_table=False):
+    # ---- cache of the temperature-only transcendentals ("K-cache")
+    KC_THR = 2.0**-9      # |d| <= 2^-9: the degree-4 Taylor sum of e^d is exact to 2.4e-16, log1p to degree 5 to 1e-17
+    _EXP_ROOTS = {"exp": (1.0, 1.0), "expn": (-1.0, 1.0), "exp10": (1.0, math.log(10.0)),
+                  "exp10n": (-1.0, math.log(10.0)), "exp2": (1.0, math.log(2.0)), "exp2n": (-1.0, math.log(2.0))}
+
+    def kcache_plan(self):
+        """Which nodes of the DAG are worth caching per mesh node between right-hand-side evaluations.
+
+        Rate and equilibrium constants depend on the temperature only - K = exp(f(T)), Arrhenius f = -E/(R T) - and
+        they are the expensive part of a kinetics evaluation (9 of the 13 transcendentals of the DME mechanism, 29 % of
+        the bench kernel's time), while T at a mesh node moves by millikelvins between RK stages and time steps.  With
+        K_ref = K(T_ref) kept per node,  K(T) = K_ref e^d,  d = f(T) - f(T_ref)  is a 4-term Taylor sum as long as
+        |d| <= 2^-9 (5 fp64 operations instead of 10 + a dependent table look-up); log(T) likewise through log1p.  A
+        wave whose lanes all pass that test takes the short path, otherwise the wave evaluates in full and moves its
+        reference point (cache refresh) - so the result never depends on the cache beyond the 2.4e-16 of the Taylor
+        remainder and the rounding of d (|f| 2e-16 absolute, i.e. ~1e-14 relative in K).
+
+        Returns None when there is nothing to cache, else a dict: ``roots`` (node ids, creation order), ``kind`` per
+        root ("log", ("lin", coef) = exponent linear in 1/T with that coefficient, or "gen" = exponent stored),
+        ``slot`` / ``fslot`` (cache slot of the value / of a "gen" exponent), ``slots`` (doubles per mesh node),
+        ``branch`` (nodes evaluated inside the cached section, roots included), ``prologue`` (their root-free
+        T-only ancestors, evaluated before it)."""
+        g = self.g
+        live = sorted(self.live)
+
+        def operands(i):
+            op, a, b = g.nodes[i]
+            if op in ("const", "in"):
+                return []
+            return [a] + ([b] if (b is not None and op != "powi") else [])
+        tonly = {}
+        for i in live:
+            op, a, b = g.nodes[i]
+            tonly[i] = True if op == "const" else ((a == "T") if op == "in" else all(tonly[o] for o in operands(i)))
+        roots = []
+        for i in live:
+            op, a, b = g.nodes[i]
+            if op in self._EXP_ROOTS and tonly[a] and not g.is_const(a):
+                roots.append(i)
+            elif op == "log" and g.nodes[a] == ("in", "T", None):
+                roots.append(i)
+        if not roots:
+            return None
+        rootset = set(roots)
+        dep = {}                      # depends on a root (strictly below it)
+        for i in live:
+            dep[i] = any(dep[o] or o in rootset for o in operands(i))
+        need, stack = set(), [g.nodes[r][1] for r in roots]
+        while stack:                  # ancestors of the roots' arguments
+            i = stack.pop()
+            if i in need:
+                continue
+            need.add(i)
+            stack.extend(operands(i))
+
+        def lin_in_invT(i):
+            """coefficient c if node i is exactly c/T through products with constants and negations, else None."""
+            op, a, b = g.nodes[i]
+            if op == "rcp" and g.nodes[a] == ("in", "T", None):
+                return 1.0
+            if op == "neg":
+                c = lin_in_invT(a)
+                return None if c is None else -c
+            if op == "mul":
+                for k, x in ((a, b), (b, a)):
+                    if g.is_const(k):
+                        c = lin_in_invT(x)
+                        if c is not None:
+                            return g.cval(k)*c
+            if op == "div" and g.is_const(a) and g.nodes[b] == ("in", "T", None):
+                return g.cval(a)
+            return None
+        kind, slot, fslot, nslots = {}, {}, {}, 1          # slot 0: 1/T_ref
+        for r in roots:
+            op, a, b = g.nodes[r]
+            slot[r] = nslots
+            nslots += 1
+            if op == "log":
+                kind[r] = "log"
+                continue
+            c = lin_in_invT(a)
+            if c is not None and math.isfinite(c) and c != 0.0:
+                kind[r] = ("lin", c)
+            else:
+                kind[r] = "gen"
+                fslot[r] = nslots
+                nslots += 1
+        branch = [i for i in live if i in rootset or (i in need and dep[i] and not g.is_const(i))]
+        prologue = [i for i in live if i in need and not dep[i] and i not in rootset]
+        return {"roots": roots, "kind": kind, "slot": slot, "fslot": fslot, "slots": nslots, "branch": branch,
+                "prologue": prologue}
+
+    def emit(self, fname="rmt_kinetics", const_table=False, kcache=False):
+        """The device function of the rates.  ``kcache``: with the cached section of kcache_plan() for callers that
+        pass a cache (template parameter KC with KC::enabled; every other caller passes rmt_nocache_t and gets the
+        plain evaluation - the section is discarded at compile time)."""
         self._const_table = {} if const_table else None
-        lines, name = self._emit_body()
+        plan = self.kcache_plan() if kcache else None
+        if plan is None:
+            lines, name = self._emit_body()
+        else:
+            lines, name = self._emit_cached(plan)
         table, self._const_table = self._const_table, None
         body = "\n".join(lines)
         if table:
@@ -870,13 +979,120 @@ class Lowered:
         else:
             self._table_decl = ""
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
-        return self._table_decl + (
-            "template <typename FL>\n"
+        head = "#define RMT_KC_SLOTS %d\n" % (plan["slots"] if plan else 0)
+        stale = self._emit_stale(plan)
+        return head + self._table_decl + stale + (
+            "template <typename FL, typename KC, int MODE = 0>\n"
             "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
             "        const real* __restrict__ x, const real* __restrict__ C, const real* __restrict__ U,\n"
-            "        real* __restrict__ r, FL& flag) {\n"
-            "    (void)invT; (void)U;\n%s\n%s\n}\n"
+            "        real* __restrict__ r, FL& flag, KC& kc) {\n"
+            "    (void)invT; (void)U; (void)kc;\n%s\n%s\n}\n"
             % (fname, body, outs))
+
+    def _emit_stale(self, plan):
+        """rmt_kinetics_stale(T, 1/T, cache): true when this node's cache cannot serve the state - not filled yet, or
+        T so far from the reference point that an exponent LINEAR in 1/T (Arrhenius) or log(T) leaves the Taylor range.
+        The caller ORs it over the wave and picks MODE 0 (full evaluation, moves the reference point) or MODE 1."""
+        if plan is None:
+            return ("template <typename KC>\n__device__ __forceinline__ bool rmt_kinetics_stale(const real, const real, "
+                    "const KC&) { return false; }\n")
+        g = self.g
+        lin = [abs(self._EXP_ROOTS[g.nodes[r][0]][0]*self._EXP_ROOTS[g.nodes[r][0]][1]*plan["kind"][r][1])
+               for r in plan["roots"] if isinstance(plan["kind"][r], tuple)]
+        tests = []
+        if lin:
+            tests.append("!(rmt_abs(invT - it_) <= real(%r))" % (self.KC_THR/max(lin)))
+        if any(k == "log" for k in plan["kind"].values()):
+            tests.append("!(rmt_abs(T * it_ - real(1)) <= real(%r))" % self.KC_THR)
+        return ("template <typename KC>\n"
+                "__device__ __forceinline__ bool rmt_kinetics_stale(const real T, const real invT, const KC& kc) {\n"
+                "    (void)T; (void)invT;\n"
+                "    if (!kc.valid) return true;\n"
+                "    const real it_ = kc.get(0);\n"
+                "    (void)it_;\n"
+                "    return %s;\n}\n" % (" || ".join(tests) if tests else "false"))
+
+    def _emit_cached(self, plan):
+        """Body with the cached section: MODE 1 (the caller has checked rmt_kinetics_stale for the whole wave) takes every
+        cached constant from its reference value by a Taylor step - exponents that are not linear in 1/T test their own
+        |d| and, when a lane of the wave is out of range, are evaluated in full and move their own reference point;
+        MODE 0 evaluates in full and (with a cache) stores the new reference point."""
+        g = self.g
+        emit = self._emitter()
+        lines, name = [], {}
+        for i in sorted(self.live):                       # constants and inputs have no code: name them first
+            if g.nodes[i][0] in ("const", "in"):
+                emit(i, name)
+        done = set(name)
+        for i in plan["prologue"]:
+            if i not in done:
+                lines.extend(emit(i, name))
+                done.add(i)
+        for i in plan["branch"]:                          # values that leave the cached section
+            lines.append("    real v%d;" % i)
+        thr = repr(self.KC_THR)
+        taylor = ("k_ + (k_ * d_) * (real(1) + d_ * (real(0.5) + d_ * (real(%r) + d_ * real(%r))))"
+                  % (1.0/6.0, 1.0/24.0))
+        L = lines.append
+        L("    if constexpr (KC::enabled && MODE == 1) {      // every constant from its cached value: K = K_ref e^d, d = f(T) - f(T_ref)")
+        L("        const real kc_it = kc.get(0);")
+        L("        const real kc_di = invT - kc_it;")
+        L("        (void)kc_di;")
+        for i in plan["branch"]:
+            op, a, b = g.nodes[i]
+            v = "v%d" % i
+            if i not in plan["kind"]:
+                for ln in emit(i, name, declare=False, nocheck=True):
+                    L("    " + ln)
+                continue
+            k = plan["kind"][i]
+            if k == "log":
+                L("        {   // log(T) = log(T_ref) + log1p(T/T_ref - 1)")
+                L("            const real s_ = T * kc_it - real(1);")
+                L("            %s = kc.get(%d) + s_ * (real(1) + s_ * (real(-0.5) + s_ * (real(%r) + s_ * (real(-0.25) + s_ * real(0.2)))));"
+                  % (v, plan["slot"][i], 1.0/3.0))
+                L("        }")
+            elif isinstance(k, tuple):
+                sg, lnb = self._EXP_ROOTS[op]
+                L("        {")
+                L("            const real d_ = real(%r) * kc_di;" % (sg*lnb*k[1]))
+                L("            const real k_ = kc.get(%d);" % plan["slot"][i])
+                L("            %s = %s;" % (v, taylor))
+                L("        }")
+            else:
+                sg, lnb = self._EXP_ROOTS[op]
+                L("        {")
+                L("            const real d_ = real(%r) * (%s - kc.get(%d));" % (sg*lnb, name[a], plan["fslot"][i]))
+                L("            if (KC::any(!(rmt_abs(d_) <= real(%s)))) {      // out of range in some lane: this constant in full," % thr)
+                name_i = dict(name)
+                for ln in emit(i, name_i, declare=False, nocheck=True):        # and its own reference point moves
+                    L("            " + ln)
+                L("                kc.put(%d, %s);" % (plan["slot"][i], v))
+                L("                kc.put(%d, %s);" % (plan["fslot"][i], name[a]))
+                L("            } else {")
+                L("                const real k_ = kc.get(%d);" % plan["slot"][i])
+                L("                %s = %s;" % (v, taylor))
+                L("            }")
+                L("        }")
+            name[i] = v
+        L("    } else {                 // full evaluation; with a cache its reference point moves here")
+        for i in plan["branch"]:
+            for ln in emit(i, name, declare=False):
+                L("    " + ln)
+            done.add(i)
+        L("        if constexpr (KC::enabled) {")
+        L("            kc.put(0, invT);")
+        for r in plan["roots"]:
+            L("            kc.put(%d, v%d);" % (plan["slot"][r], r))
+            if r in plan["fslot"]:
+                L("            kc.put(%d, %s);" % (plan["fslot"][r], name[g.nodes[r][1]]))
+        L("        }")
+        L("    }")
+        for i in sorted(self.live):
+            if i not in done:
+                lines.extend(emit(i, name))
+                done.add(i)
+        return lines, name
 
 
 class Gradient(Lowered):

@@ -124,6 +124,14 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
         specialize = E >= 2
     if specialize:
         defs.update(plan.uniform_member_defines(members, mech.S))
+    # "RMT_KCACHE": "1" in `defines` (opt-in experiment, see lowering.Lowered.kcache_plan): the on-chip RK4 stepper
+    # caches the temperature-only rate constants per node in LDS.  Measured SLOWER on MI355X (1.28e10 vs 1.62e10
+    # node-steps/s on the bench shape, profiles/round3_kcache.md): the 512 x 2 kernel sits at exactly 256 VGPRs with no
+    # spill, the second code path costs 60 spilled VGPRs, and at two waves per SIMD every scratch access is exposed.
+    if str(defs.get("RMT_KCACHE", "0")) == "1" and not (int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state)):
+        raise ValueError("RMT_KCACHE=1: the cache of the temperature-only rate constants (%d doubles per node) does not "
+                         "fit this geometry (needs the on-chip RK4 stepper with its vectors in registers, model N2, fp64)"
+                         % mech.kcache_slots())
     tpl = hipbind.kernel_template()
     # (the user's lds_state, possibly None, is what selects the per-kernel defaults)
     src = mech.source(tpl, fp32, block, npt, lds_state, defs)
@@ -522,6 +530,7 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
     and broadcasts; pass the same E/block/npt/lds_state/defines to N2Device(code=...)."""
     b, n = choose_geometry(N, mech.V, fp32, E)
     block, npt = int(block or b), int(npt or n)
+    defines = dict(defines or {})
     tpl = hipbind.kernel_template()
     return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, lds_state, defines),
                                   mech.digest(tpl, fp32, block, npt, lds_state, defines), arch, extra_opts)

@@ -247,11 +247,26 @@ class Mechanism:
             #                                              node-steps/s with 1 / 2 / 0 vectors in LDS)
         return fit
 
+    def kcache_slots(self):
+        """doubles per mesh node the cache of the temperature-only rate constants needs (0: nothing to cache)."""
+        p = self.device_dag().kcache_plan()
+        return p["slots"] if p else 0
+
+    def kcache_fits(self, fp32, block, npt, lds_state=None):
+        """True when the on-chip RK4 stepper can keep that cache in LDS: model N2 in fp64, its RK4 vectors in
+        registers (lds_state 0) and slots x nodes-per-workgroup doubles beside the exp table (16 KiB; 512 B for
+        one-wave workgroups) and the exchange buffers within 150 KiB."""
+        slots = self.kcache_slots()
+        if not slots or fp32 or self.model != "N2" or self.lds_state(fp32, block, npt, lds_state) != 0:
+            return False
+        return slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
+
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
         if "RMT_KINETICS_SOURCE" not in template:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
-        kin = self.device_dag().emit("rmt_kinetics", const_table=bool((defines or {}).get("RMT_KINETICS_KTAB")))
+        kin = self.device_dag().emit("rmt_kinetics", const_table=bool((defines or {}).get("RMT_KINETICS_KTAB")),
+                                     kcache=str((defines or {}).get("RMT_KCACHE", "0")) == "1")
         if (defines or {}).get("RMT_WITH_ROS4"):
             # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i
             kin += self.device_dag().gradient().emit_jac("rmt_kinetics_jac")

@@ -671,3 +671,27 @@ def test_tiny_and_wave_boundary_meshes_vs_oracle(N):
     assert rowwise_err(y.cpu().numpy()[0], want, mech.V) < 1e-12
     assert not dev.status().any()
     dev.close()
+
+
+def test_kcache_opt_in_matches_the_shipped_kernel():
+    """defines={"RMT_KCACHE": "1"} (opt-in: the temperature-only rate constants cached per node, a Taylor step in
+    d = f(T) - f(T_ref) while |d| <= 2^-9, full evaluation + new reference point otherwise): same trajectory as the
+    shipped on-chip RK4 kernel to rounding, over steps small enough to stay on the short path and over steps that
+    leave the Taylor range every stage (the refresh path), and the oracle's RK4."""
+    N = 200
+    mi, mech, nm, dev = make_device("dme_nb", N, E=3, block=128, npt=2)
+    _, _, _, devc = make_device("dme_nb", N, E=3, block=128, npt=2, defines={"RMT_KCACHE": "1"})
+    IV = np.tile(plan.initial_state(nm, mech, N), (3, 1))
+    for dt, n in ((2e-6, 400), (2.5e-5, 40)):
+        y, yc = dev.to_device(IV), devc.to_device(IV)
+        dev.rk4(y, dt, n)
+        devc.rk4(yc, dt, n)
+        assert not dev.status().any() and not devc.status().any()
+        a, b = y.cpu().numpy(), yc.cpu().numpy()
+        for e in range(3):
+            assert rowwise_err(b[e], a[e], mech.V) < 1e-12, (dt, e)
+    pr = O.setup_n2(mi, N)
+    want = O.rk4(0.0, 40*2.5e-5, 40, pr["IV"], O.make_rhs_vec(pr), keep=False)
+    assert rowwise_err(b[0], want, mech.V) < 1e-11
+    dev.close()
+    devc.close()

@@ -660,3 +660,31 @@ def test_ensemble_output_outlet_keeps_only_the_last_node():
             assert b["dataYTemp1"][0] == a["dataYTemp1"][-1] and b["dataTime"] == a["dataTime"]
     with pytest.raises(ValueError):
         run(**{"ensemble-output": "everything"})
+
+
+# ----------------------------------------------------------------------------- K-cache (opt-in experiment)
+def test_kcache_plan_and_emission_for_the_test_mechanisms(template):
+    """lowering.Lowered.kcache_plan: the temperature-only exp / log roots of every test mechanism, their cache slots,
+    and the generated source with the cached section still builds for the host (where the section is discarded) and
+    reproduces the reference RHS."""
+    dme = plan.Mechanism(INP.dme_notebook_input())
+    p = dme.device_dag().kcache_plan()
+    kinds = [p["kind"][r] if isinstance(p["kind"][r], str) else "lin" for r in p["roots"]]
+    assert kinds.count("lin") == 6 and kinds.count("log") == 1 and kinds.count("gen") == 3 and p["slots"] == 14
+    assert dme.kcache_slots() == 14 and dme.kcache_fits(False, 512, 2) and not dme.kcache_fits(True, 512, 2)
+    syn = plan.Mechanism(INP.syn12_input())
+    assert syn.kcache_slots() == 9                         # 1/T_ref + eight Arrhenius constants
+    assert plan.Mechanism(INP.ch4_input()).kcache_slots() == 0
+    src = dme.source(template, defines={"RMT_KCACHE": "1"})
+    assert "rmt_kinetics_stale" in src and "#define RMT_KC_SLOTS 14" in src and "MODE == 1" in src
+    g = np.load(os.path.join(G, "g2_rhs.npz"))
+    Y, F = g["dme_nb_20_y"], g["dme_nb_20_f"]
+    _, row = plan.member_constants(INP.dme_notebook_input(), dme, 20)
+    out, flags = HostEmu(src, tag="dme_kc").rhs(Y, np.tile(row, (len(Y), 1)), 20)
+    assert not flags.any()
+    for k in range(len(Y)):
+        assert rowwise_err(out[k], F[k], dme.V) < 1e-12
+    from rmt_app_amd.n2 import device_source
+    with pytest.raises(ValueError):                        # the 12-species geometry keeps its RK4 vectors in LDS: no room
+        device_source(syn, row if False else plan.member_constants(INP.syn12_input(), syn, 1024)[1], 1024,
+                      defines={"RMT_KCACHE": "1"})

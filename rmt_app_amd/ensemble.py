@@ -313,7 +313,7 @@ class DistributedEnsemble:
             pairs = [pack(mi, mech, zNo) for mi in mine]
             named = [nm for nm, _ in pairs]
             rows = np.array([r for _, r in pairs]).reshape(len(mine), mech.row_width)
-            IV = np.array([init(nm, mech, zNo) for nm in named]).reshape(len(mine), mech.V*zNo)
+            IV = plan.initial_states(named, mech, zNo, init)
             return named, rows, IV
         self.named, self.rows, self.IV = local_phase(pack_mine)
         # member fields that are identical over the WHOLE ensemble become kernel literals: agree on

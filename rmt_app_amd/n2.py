@@ -590,7 +590,7 @@ def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=Non
     if sync is None:
         pairs = [pack(mi, mech, zNo) for mi in inputs]
         rows = np.array([r for _, r in pairs])
-        IV = np.array([init(nm, mech, zNo) for nm, _ in pairs])
+        IV = plan.initial_states([nm for nm, _ in pairs], mech, zNo, init)
         dev = device_cls()(mech, rows, zNo, fp32=fp32, block=block, npt=npt, defines=defines, features=features)
         return dev, [nm for nm, _ in pairs], IV
     # Multi-rank: every rank-LOCAL phase (packing, the rank-0 compile inside DistributedEnsemble, loading the

@@ -516,6 +516,16 @@ def uniform_member_defines(rows, S, vals=None, mask=None):
     return out
 
 
+def initial_states(named_list, mech, zNo, init=None):
+    """[E][V*zNo]: initial_state (or ``init``, e.g. initial_state_m2) of every member at once.  Both reference forms
+    fill each row of the (V, zNo) matrix with ONE value, so the E x V matrix of those values (taken from a 1-node
+    evaluation of the per-member function) is broadcast along the mesh - bit-identical to stacking the per-member
+    arrays, without E Python-level fills of a zNo-long matrix (0.3 ms each at zNo = 1024: 0.6 s for a 2048-member sweep)."""
+    init = init or initial_state
+    first = np.array([init(nm, mech, 1) for nm in named_list], dtype=np.float64).reshape(len(named_list), mech.V, 1)
+    return np.ascontiguousarray(np.broadcast_to(first, (len(named_list), mech.V, zNo))).reshape(len(named_list), mech.V*zNo)
+
+
 def initial_state(named, mech, zNo):
     """IV2D flattened (pbHomoReactor.py:3483-3497)."""
     IV = np.zeros((mech.V, zNo))

@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define RMT_N2_ABI_VERSION 1
+#define RMT_N2_ABI_VERSION 2
 
 /* status bits written by the kernels (OR-ed per reactor) */
 #define RMT_N2_FLAG_DOMAIN 1u    /* Python: ValueError("math domain error")          */
@@ -98,6 +98,10 @@ typedef struct rmt_n2_plan {
     int32_t block;           /* RMT_BLOCK the code object was generated with */
     int32_t nodes_per_thread;/* RMT_NPT the code object was generated with */
     int32_t n_user_params;   /* NU (RMT_NU of the code object; 0 = every VARS constant is a literal of the kernel) */
+    int32_t ros4_nodes_per_block; /* mesh nodes one workgroup of the stiff stepper covers: 0 = `block` (one node per lane);
+                              * block / 4 for code objects generated with RMT_ROS_QUAD (one node on four lanes, the
+                              * layout for mechanisms wider than 8 variables, kernels/61_ros4_quad.inc) */
+    int32_t reserved;
     const void* code_object; /* gfx950 code object from rmt_n2_compile (host memory) */
     size_t code_size;
     const double* members;   /* host [E][16+S+NU] packed constants */

@@ -39,6 +39,7 @@ static int fail(const char* fmt, ...) {
 
 struct rmt_n2_handle {
     int S = 0, V = 0, NU = 0, N = 0, E = 0, fp32 = 0, block = 0, npt = 0, mode = 0, device = 0;
+    int ros_nb = 0;                          // mesh nodes per workgroup of the stiff stepper (block, or block / 4 in the quad layout)
     size_t real_size = 8;
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
@@ -170,6 +171,8 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         return fail("block must be a multiple of 64 in [64,1024] (got %d)", p->block);
     if (p->nodes_per_thread < 1) return fail("nodes_per_thread must be >= 1");
     if (p->n_user_params < 0 || p->n_user_params > 64) return fail("n_user_params must be in [0,64] (got %d)", p->n_user_params);
+    if (p->ros4_nodes_per_block != 0 && p->ros4_nodes_per_block != p->block && p->ros4_nodes_per_block * 4 != p->block)
+        return fail("ros4_nodes_per_block must be 0, block or block / 4 (got %d for block %d)", p->ros4_nodes_per_block, p->block);
     if (!p->code_object || !p->code_size || !p->members) return fail("plan lacks code object/members");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -178,6 +181,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     h->S = p->n_species;
     h->V = p->n_vars;
     h->NU = p->n_user_params;
+    h->ros_nb = p->ros4_nodes_per_block > 0 ? p->ros4_nodes_per_block : p->block;
     h->N = p->n_nodes;
     h->E = p->n_members;
     h->fp32 = p->fp32;
@@ -454,7 +458,7 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
                     "block <= 512 (got %d)", h->block);
     // One reactor over several CUs (rmt_n2_ros4_chain): C chunks of W nodes per reactor, T teams, every
     // workgroup resident (T*C <= #CUs).  Auto mode chains when the ensemble alone cannot fill the device.
-    const int nblocks = (h->N + h->block - 1) / h->block;
+    const int nblocks = (h->N + h->ros_nb - 1) / h->ros_nb;      // node blocks per reactor
     int C = 1;
     if (h->f_ros4_chain && h->npt == 1 && nblocks >= 2 && h->mode != 2) {
         // Chunks of ONE node block pipeline stage by stage (a chunk lags its upstream neighbour by a message
@@ -490,7 +494,7 @@ extern "C" int rmt_n2_ros4(rmt_n2_handle* h, void* y, double t0, double t1, doub
     if (C >= 2) {
         const int bpc = (nblocks + C - 1) / C;          // node blocks per chunk
         C = (nblocks + bpc - 1) / bpc;
-        int W = bpc * h->block;
+        int W = bpc * h->ros_nb;
         int T = h->n_cus / C;
         if (T > h->E) T = h->E;
         if (ensure_work(h, 1)) return 1;                // y_new

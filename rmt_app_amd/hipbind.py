@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RMT_N2_LIBRARY") or os.path.join(_HERE, "librmt_n2.so")
 CACHE_DIR = os.path.join(_HERE, "_kcache")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RmtN2Error(RuntimeError):
@@ -24,7 +24,7 @@ class Plan(C.Structure):
         ("abi_version", C.c_int32), ("n_species", C.c_int32), ("n_reactions", C.c_int32),
         ("n_vars", C.c_int32), ("n_nodes", C.c_int32), ("n_members", C.c_int32),
         ("fp32", C.c_int32), ("block", C.c_int32), ("nodes_per_thread", C.c_int32),
-        ("n_user_params", C.c_int32),
+        ("n_user_params", C.c_int32), ("ros4_nodes_per_block", C.c_int32), ("reserved", C.c_int32),
         ("code_object", C.c_void_p), ("code_size", C.c_size_t), ("members", C.POINTER(C.c_double)),
     ]
 

@@ -58,7 +58,7 @@ def run_m2(modelInput, members_inputs=None):
     sync = active_ranks(len(inputs)) if members_inputs else None       # one rank of a torchrun job?
     block, npt = cfg.get('block'), cfg.get('nodes-per-thread')
     if ivp == "hip-ros4" and block is None:
-        block, npt = ros4_block(mech.V, zNo), 1
+        block, npt = ros4_block(mech.V, zNo, quad=False), 1
     defines = {}
     if ivp == "hip-rk45" and block is None:
         block, npt, defines = rk45_geometry(mech.V, zNo, E=len(inputs) if sync is None else max(sync.counts))

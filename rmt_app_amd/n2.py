@@ -43,10 +43,20 @@ def choose_geometry(N, V, fp32=False, E=None):
     return (512, 2) if V <= 8 else (512, 1)
 
 
-def ros4_block(V, N, fp32=False):
+def ros4_quad(mech, fp32=False):
+    """True when the stiff stepper runs in its one-node-on-four-lanes layout (kernels/61_ros4_quad.inc): mechanisms
+    wider than 8 variables, whose V x V node inverse does not fit one lane's registers (model N2, fp64)."""
+    return mech.V > 8 and getattr(mech, "model", "N2") == "N2" and not fp32
+
+
+def ros4_block(V, N, fp32=False, quad=None):
     """Workgroup size for the stiff stepper: at most 256 threads (one V x V block inverse per lane),
     and the block's five stage vectors G_1..G_5 must fit in LDS next to the 16 KiB exp table and the
-    hand-over buffers (5*V*block*sizeof(real) <= 140 KiB)."""
+    hand-over buffers (5*V*block*sizeof(real) <= 140 KiB).  (Quad layout, V > 8 in fp64: 256 threads = 64 nodes.)"""
+    if quad is None:
+        quad = V > 8 and not fp32
+    if quad:
+        return 256 if N > 32 else 64*((4*N + 63)//64)
     block = min(256, 64*((N + 63)//64))
     while block > 64 and 5*V*block*(4 if fp32 else 8) > 140*1024:
         block //= 2
@@ -116,6 +126,8 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
     # unrolled VxV linear algebra is most of the JIT time, so they are compiled on demand
     for f in features:
         defs[FEATURE_DEFINES[f]] = "1"
+    if "ros4" in features and "RMT_ROS_QUAD" not in defs and ros4_quad(mech, fp32) and npt == 1:
+        defs["RMT_ROS_QUAD"] = "1"            # wide mechanism: one node on four lanes (the C library is told below)
     if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in defs and not have_code:
         defs["RMT_M2_NEWTON"] = str(plan.m2_newton_sweeps(members, mech, int(N)))
     # sweep-invariant member fields become literals (frees SGPRs); a single reactor is NOT
@@ -185,6 +197,8 @@ class N2Device:
         p.n_nodes, p.n_members, p.fp32 = self.N, self.E, int(self.fp32)
         p.block, p.nodes_per_thread = self.block, self.npt
         p.n_user_params = mech.NU
+        self.ros_quad = str(self.defines.get("RMT_ROS_QUAD", "0")) == "1"
+        p.ros4_nodes_per_block = self.block//4 if self.ros_quad else 0
         p.code_object = C.cast(self._code, C.c_void_p)
         p.code_size = len(code)
         p.members = members.ctypes.data_as(C.POINTER(C.c_double))
@@ -603,6 +617,8 @@ def open_members(mech, inputs, zNo, pack, init, sync=None, fp32=False, block=Non
     defs = dict(defines or {})
     for f in features:
         defs[FEATURE_DEFINES[f]] = "1"
+    if "ros4" in features and "RMT_ROS_QUAD" not in defs and ros4_quad(mech, fp32) and npt == 1:
+        defs["RMT_ROS_QUAD"] = "1"
     if getattr(mech, "model", "N2") == "M2" and "RMT_M2_NEWTON" not in defs:
         sweeps = guarded(sync, lambda: plan.m2_newton_sweeps(
             np.array([pack(mi, mech, zNo)[1] for mi in inputs[sync.lo:sync.hi]]), mech, zNo))

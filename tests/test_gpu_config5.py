@@ -252,3 +252,39 @@ def test_auto_switches_to_the_stiff_stepper_when_the_bed_heats_up():
     a = res["dataPack"][-1]["dataYs"]
     b = rmtExe(ref)["resModel"]["dataPack"][-1]["dataYs"]
     assert np.max(np.abs(a - b)/np.abs(b)) < 2e-6
+
+
+# ----------------------------------------------------------------------------- stiff stepper, wide mechanism (one node on four lanes)
+@pytest.mark.parametrize("N,mode", [(40, "mem"), (150, "mem"), (150, "chain")])
+def test_ros4_quad_layout_vs_oracle_controller(N, mode):
+    """The 12-species mechanism (13 x 13 node blocks) runs the stiff stepper in its one-node-on-four-lanes layout
+    (kernels/61_ros4_quad.inc: matrix rows split over a quad, the iterate through LDS).  Against the oracle's RODAS4
+    controller (exact bidiagonal solves): same step history, same end state - for a mesh inside one workgroup, one that
+    walks several node blocks with a ragged tail (150 = 64 + 64 + 22), and the same mesh chained over three CUs; two
+    reactors with their own step sequences."""
+    from rmt_app_amd.n2 import N2Device, ros4_block
+    mech = plan.Mechanism(INP.syn12_input())
+    assert ros4_block(mech.V, N) == 256 and ros4_block(mech.V, 20) == 128        # 64 / 32 nodes per workgroup
+    mis, rows, ivs = [], [], []
+    for T in (600.0, 615.0):
+        mi = INP.syn12_input()
+        mi["operating-conditions"]["temperature"] = T
+        nm, row = plan.member_constants(mi, mech, N)
+        mis.append(mi), rows.append(row), ivs.append(plan.initial_state(nm, mech, N))
+    dev = N2Device(mech, np.array(rows), N, block=ros4_block(mech.V, N), npt=1, features=("ros4",))
+    assert dev.ros_quad and dev.defines["RMT_ROS_QUAD"] == "1"
+    dev.set_mode(mode)
+    y = dev.to_device(np.array(ivs))
+    rtol, atol, h0, t1 = 1e-6, 1e-9, 1e-5, 0.05
+    dev.ros4(y, 0.0, t1, rtol, atol, h0, 10**6)
+    assert not dev.status().any()
+    assert dev.last_geometry()[0] == (1 if mode == "mem" else 3)
+    st, got = dev.rk45_stats(), y.cpu().numpy()
+    for e, mi in enumerate(mis):
+        pr = O.setup_n2(mi, N)
+        want, ost = O.ros4(pr, pr["IV"], 0.0, t1, rtol, atol, h0, scheme="rodas4")
+        assert st["t_end"][e] == t1
+        assert abs(int(st["accepted"][e]) - ost["accepted"]) <= max(3, 0.03*ost["accepted"]), (e, st, ost)
+        scale = np.max(np.abs(want.reshape(13, N)), axis=1, keepdims=True)
+        assert np.max(np.abs(got[e].reshape(13, N) - want.reshape(13, N))/scale) < 20*rtol, e
+    dev.close()

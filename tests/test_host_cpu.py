@@ -48,7 +48,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(hipbind.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert hipbind.lib().rmt_n2_abi_version() == 1
+    assert hipbind.lib().rmt_n2_abi_version() == hipbind.ABI_VERSION == 2
     # the embedded device template = the per-family files of csrc/kernels/ in the order of kernels/ORDER
     tpl = hipbind.kernel_template()
     kdir = os.path.join(ROOT, "rmt_app_amd", "csrc", "kernels")
@@ -688,3 +688,28 @@ def test_kcache_plan_and_emission_for_the_test_mechanisms(template):
     with pytest.raises(ValueError):                        # the 12-species geometry keeps its RK4 vectors in LDS: no room
         device_source(syn, row if False else plan.member_constants(INP.syn12_input(), syn, 1024)[1], 1024,
                       defines={"RMT_KCACHE": "1"})
+
+
+# ----------------------------------------------------------------------------- stiff stepper, quad layout (V > 8)
+def test_ros4_quad_layout_has_no_sweep_loop_spills():
+    """What the layout is for: the code object of the 12-species stiff stepper keeps the sweep loops free of scratch
+    accesses (the node-per-lane kernel spilled 1000-1500 VGPRs per lane, 2-3.8 KB of scratch)."""
+    import re
+    import subprocess
+    import tempfile
+    from rmt_app_amd import hipbind
+    from rmt_app_amd.n2 import device_source
+    mech = plan.Mechanism(INP.syn12_input())
+    _, row = plan.member_constants(INP.syn12_input(), mech, 512)
+    _, _, defs, src, key = device_source(mech, np.tile(row, (64, 1)), 512, block=256, npt=1, features=("ros4",))
+    assert defs["RMT_ROS_QUAD"] == "1"
+    blob = hipbind.compile_cached(src, key, "gfx950")
+    with tempfile.NamedTemporaryFile(suffix=".hsaco") as f:
+        f.write(blob)
+        f.flush()
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", f.name], capture_output=True,
+                               text=True, check=True).stdout
+    for kern in ("rmt_n2_ros4_mem", "rmt_n2_ros4_chain"):
+        blk = [b for b in notes.split("- .agpr_count") if ".name:           %s" % kern in b or re.search(r"\.name:\s+%s\b" % kern, b)][0]
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        assert scratch < 1024, (kern, scratch)           # the once-per-step Jacobian assembly still spills a little

@@ -261,12 +261,22 @@ class Mechanism:
             return False
         return slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
 
+    def kcache_fits_chain(self, fp32, block, npt, lds_state=None):
+        """The same cache in the chained RK4 stepper (RMT_KCACHE_CHAIN): beside the chunk's RK4 vectors in LDS; worth it
+        where a stage is latency-bound - one node per lane, small chunks (one wave per SIMD, registers to spare)."""
+        slots = self.kcache_slots()
+        if not slots or fp32 or self.model != "N2" or npt != 1 or block > 256:
+            return False
+        state = self.lds_state(fp32, block, npt, lds_state, chained=True)*self.V*block*npt*8
+        return state + slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
+
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
         if "RMT_KINETICS_SOURCE" not in template:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
         kin = self.device_dag().emit("rmt_kinetics", const_table=bool((defines or {}).get("RMT_KINETICS_KTAB")),
-                                     kcache=str((defines or {}).get("RMT_KCACHE", "0")) == "1")
+                                     kcache=(str((defines or {}).get("RMT_KCACHE", "0")) == "1"
+                                             or str((defines or {}).get("RMT_KCACHE_CHAIN", "0")) == "1"))
         if (defines or {}).get("RMT_WITH_ROS4"):
             # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i
             kin += self.device_dag().gradient().emit_jac("rmt_kinetics_jac")

@@ -32,7 +32,7 @@ def test_plain_ctypes_roundtrip():
     assert L.rmt_n2_compile(src.encode(), b"gfx950", b"", C.byref(code), C.byref(size), C.byref(log)) == 0
 
     p = hipbind.Plan()
-    p.abi_version, p.n_species, p.n_reactions, p.n_vars = 1, mech.S, mech.R, mech.V
+    p.abi_version, p.n_species, p.n_reactions, p.n_vars = hipbind.ABI_VERSION, mech.S, mech.R, mech.V
     p.n_nodes, p.n_members, p.fp32, p.block, p.nodes_per_thread = N, 1, 0, block, npt
     p.code_object, p.code_size = code, size
     rows = np.ascontiguousarray(row.reshape(1, -1))
@@ -88,7 +88,7 @@ def test_plain_ctypes_stiff_stepper_and_stats():
     code, size, log = C.c_void_p(), C.c_size_t(), C.c_void_p()
     assert L.rmt_n2_compile(src.encode(), b"gfx950", b"", C.byref(code), C.byref(size), C.byref(log)) == 0
     p = hipbind.Plan()
-    p.abi_version, p.n_species, p.n_reactions, p.n_vars = 1, mech.S, mech.R, mech.V
+    p.abi_version, p.n_species, p.n_reactions, p.n_vars = hipbind.ABI_VERSION, mech.S, mech.R, mech.V
     p.n_nodes, p.n_members, p.fp32, p.block, p.nodes_per_thread = N, 1, 0, 64, 1
     p.code_object, p.code_size = code, size
     rows = np.ascontiguousarray(row.reshape(1, -1))

@@ -64,7 +64,7 @@ def test_create_rejects_bad_plans_and_reports_errors():
     h = ctypes.c_void_p()
     assert L.rmt_n2_create(ctypes.byref(p), ctypes.byref(h)) != 0
     assert b"ABI version" in L.rmt_n2_last_error()
-    p.abi_version = 1
+    p.abi_version = hipbind.ABI_VERSION
     assert L.rmt_n2_create(ctypes.byref(p), ctypes.byref(h)) != 0
     assert b"bad plan sizes" in L.rmt_n2_last_error()
     with pytest.raises(hipbind.RmtN2Error):

@@ -26,4 +26,6 @@ tools/prof_cmd.sh $tag/rk45_chain tools/run_one.py rk45 dme_nb 4096 64 4e-3 512 
 tools/prof_cmd.sh $tag/rk4_chain_e1 tools/run_one.py rk4 dme_nb 4096 1 2000
 tools/prof_cmd.sh $tag/rk4_chain_e256 tools/run_one.py rk4 dme_nb 4096 256 200
 tools/prof_cmd.sh $tag/rk4_syn12 tools/run_one.py rk4 syn12 512 256 1000
+tools/prof_cmd.sh $tag/ros4_quad_syn12 tools/run_one.py ros4 syn12 512 64 2.0 256 1
+tools/prof_cmd.sh $tag/ros4_quad_syn12_mem tools/run_one.py ros4 syn12 512 64 2.0 256 1 mem
 echo "all profiles done"

@@ -679,8 +679,8 @@ def test_kcache_opt_in_matches_the_shipped_kernel():
     shipped on-chip RK4 kernel to rounding, over steps small enough to stay on the short path and over steps that
     leave the Taylor range every stage (the refresh path), and the oracle's RK4."""
     N = 200
-    mi, mech, nm, dev = make_device("dme_nb", N, E=3, block=128, npt=2)
-    _, _, _, devc = make_device("dme_nb", N, E=3, block=128, npt=2, defines={"RMT_KCACHE": "1"})
+    mi, mech, nm, dev = make_device("dme_nb", N, E=3, block=128, npt=2, lds_state=0)
+    _, _, _, devc = make_device("dme_nb", N, E=3, block=128, npt=2, lds_state=0, defines={"RMT_KCACHE": "1"})
     IV = np.tile(plan.initial_state(nm, mech, N), (3, 1))
     for dt, n in ((2e-6, 400), (2.5e-5, 40)):
         y, yc = dev.to_device(IV), devc.to_device(IV)

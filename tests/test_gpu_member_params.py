@@ -132,3 +132,47 @@ def test_n1_and_m2_sweeps_with_a_parameter_column():
         one["reaction-rates"]["VARS"]["CaBeDe"] = CABEDE[e]
         single = rmtExe(one)["resModel"]["dataPack"]
         np.testing.assert_allclose(ens[e]["dataPack"][0]["dataYs"], single[0]["dataYs"], rtol=1e-11)
+
+
+def test_parameter_columns_can_be_changed_without_recompiling():
+    """solver-config "vars-as-parameters" semantics at the device level: a code object built with CaBeDe as a run-time
+    parameter integrates a NEW value after rmt_n2_set_members - no recompilation - and equals a fresh device."""
+    N = 96
+    base = INP.dme_notebook_input()
+    mech = plan.Mechanism(base, params=["CaBeDe"])
+
+    def row_for(v):
+        mi = INP.dme_notebook_input()
+        mi["reaction-rates"]["VARS"]["CaBeDe"] = v
+        return plan.member_constants(mi, mech, N)
+    (nm, r0), (_, r1) = row_for(1171.2), row_for(700.0)
+    IV = np.tile(plan.initial_state(nm, mech, N), (2, 1))
+    dev = N2Device(mech, np.array([r0, r0]), N, specialize=False)
+    dev.set_members(np.array([r1, r0]))
+    y = dev.to_device(IV)
+    dev.rk4(y, 2e-6, 60)
+    fresh = N2Device(mech, np.array([r1, r0]), N, specialize=False)
+    y2 = fresh.to_device(IV)
+    fresh.rk4(y2, 2e-6, 60)
+    a = y.cpu().numpy()
+    np.testing.assert_array_equal(a, y2.cpu().numpy())
+    assert np.max(np.abs(a[0] - a[1])) > 1e-9
+    dev.close()
+    fresh.close()
+
+
+def test_ensemble_output_outlet_on_the_device():
+    """solver-config "ensemble-output": "outlet": the outlet column of the full-profile run, bit for bit, for a sweep that
+    also varies a kinetic constant."""
+    def run(**extra):
+        mi = INP.dme_notebook_input(ivp="hip-ros4", period=0.02)
+        mi["solver-config"].update(dict({"quiet": True, "zNo": 128, "tNo": 2}, **extra))
+        mi["solver-config"]["ensemble"] = [{"reaction-rates": {"VARS": {"CaBeDe": v}},
+                                            "operating-conditions": {"temperature": T}}
+                                           for v, T in ((1171.2, 523.0), (800.0, 533.0), (1500.0, 513.0))]
+        return rmtExe(mi)["resModel"]["ensemble"]
+    full, out = run(), run(**{"ensemble-output": "outlet"})
+    for f, o in zip(full, out):
+        for k in range(2):
+            assert o["dataPack"][k]["dataYs"].shape == (7, 1)
+            np.testing.assert_array_equal(o["dataPack"][k]["dataYs"][:, 0], f["dataPack"][k]["dataYs"][:, -1])

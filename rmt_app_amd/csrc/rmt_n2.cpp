@@ -21,6 +21,10 @@ static const char* const k_template =
 
 static thread_local std::string g_err;
 
+// workgroups per CU the single-evaluation kernel rmt_n2_rhs is launched with at most (it loops over the reactors): enough
+// to fill every wave slot the kernel's registers allow (4 per SIMD at 256 threads), with a second set queued behind
+#define RMT_N2_RHS_WGS_PER_CU 8
+
 static int fail(const char* fmt, ...) {
     char buf[2048];
     va_list ap;
@@ -332,9 +336,16 @@ extern "C" int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt)
     (void)t; /* the N2 right-hand side is autonomous (pbHomoReactor.py:3706: t unused) */
     if (!h || !y || !dydt) return fail("null argument");
     ON_DEVICE(h);
-    int N = h->N;
-    void* args[] = {(void*)&y, (void*)&dydt, (void*)&h->d_members, (void*)&N, (void*)&h->d_flags};
-    return launch(h, h->f_rhs, args);
+    int N = h->N, E = h->E;
+    void* args[] = {(void*)&y, (void*)&dydt, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&h->d_flags};
+    // persistent workgroups: at most RMT_N2_RHS_WGS_PER_CU per CU, each walking reactors e, e + grid, ...
+    static const int per_cu = [] {               // tuning override, read once
+        const char* v = getenv("RMT_N2_RHS_WGS_PER_CU");
+        const int n = v ? atoi(v) : 0;
+        return n > 0 ? n : RMT_N2_RHS_WGS_PER_CU;
+    }();
+    const long long cap = (long long)h->n_cus * per_cu;
+    return launch(h, h->f_rhs, args, h->E < cap ? h->E : (int)cap);
 }
 
 static bool fits_registers(const rmt_n2_handle* h) { return h->N <= h->block * h->npt; }

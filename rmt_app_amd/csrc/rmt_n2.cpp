@@ -48,7 +48,7 @@ struct rmt_n2_handle {
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
                   f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr, f_n1 = nullptr,
-                  f_ros4_chain = nullptr, f_rk45_chain = nullptr;
+                  f_ros4_chain = nullptr, f_rk45_chain = nullptr, f_rk4_redo = nullptr;
     unsigned long long* d_rings = nullptr;   // tagged-word links of the chained stiff stepper: rings, decision slots, abort words
     size_t ring_bytes = 0;
     double* d_members1 = nullptr;
@@ -206,6 +206,10 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     CREATE_OK(hipModuleGetFunction(&h->f_rhs, h->module, "rmt_n2_rhs"));
     CREATE_OK(hipModuleGetFunction(&h->f_rk4_reg, h->module, "rmt_n2_rk4_reg"));
     CREATE_OK(hipModuleGetFunction(&h->f_rk4_mem, h->module, "rmt_n2_rk4_mem"));
+    // code objects whose on-chip RK4 stepper caches the temperature-only rate constants (RMT_KCACHE) carry the plain
+    // stepper as a second kernel: it re-integrates the reactors the cached one gave up on
+    if (hipModuleGetFunction(&h->f_rk4_redo, h->module, "rmt_n2_rk4_reg_redo") != hipSuccess)
+        h->f_rk4_redo = nullptr;
     if (hipModuleGetFunction(&h->f_rk45_reg, h->module, "rmt_n2_rk45_reg") != hipSuccess)
         h->f_rk45_reg = nullptr;
     if (hipModuleGetFunction(&h->f_rk45_mem, h->module, "rmt_n2_rk45_mem") != hipSuccess)
@@ -305,12 +309,16 @@ static int ensure_rings(rmt_n2_handle* h, int T, int C, unsigned long long** dec
     return 0;
 }
 
-static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1, int chunks = 1, int teams = 0) {
+static int launch(rmt_n2_handle* h, hipFunction_t f, void** args, int grid = -1, int chunks = 1, int teams = 0,
+                  hipFunction_t then = nullptr) {
     h->last_chunks = chunks;
     h->last_teams = teams > 0 ? teams : h->E;
     HIP_OK(hipEventRecord(h->ev0, h->stream));
     HIP_OK(hipModuleLaunchKernel(f, (unsigned)(grid > 0 ? grid : h->E), 1, 1, (unsigned)h->block, 1, 1, 0,
                                  h->stream, args, nullptr));
+    if (then)          // a follow-up kernel with the same arguments and geometry, inside the timed region
+        HIP_OK(hipModuleLaunchKernel(then, (unsigned)(grid > 0 ? grid : h->E), 1, 1, (unsigned)h->block, 1, 1, 0,
+                                     h->stream, args, nullptr));
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
     return 0;
@@ -364,7 +372,7 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
                         h->block * h->npt, h->N);
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&dt, (void*)&ns,
                         (void*)&h->d_flags};
-        return launch(h, h->f_rk4_reg, args);
+        return launch(h, h->f_rk4_reg, args, -1, 1, 0, h->f_rk4_redo);
     }
     // chained workgroups: C chunks per reactor, T teams, every workgroup resident (T*C <= #CUs)
     const int W = h->block * h->npt;

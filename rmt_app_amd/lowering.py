@@ -872,7 +872,7 @@ class Lowered:
     _EXP_ROOTS = {"exp": (1.0, 1.0), "expn": (-1.0, 1.0), "exp10": (1.0, math.log(10.0)),
                   "exp10n": (-1.0, math.log(10.0)), "exp2": (1.0, math.log(2.0)), "exp2n": (-1.0, math.log(2.0))}
 
-    def kcache_plan(self):
+    def kcache_plan(self, gen=True):
         """Which nodes of the DAG are worth caching per mesh node between right-hand-side evaluations.
 
         Rate and equilibrium constants depend on the temperature only - K = exp(f(T)), Arrhenius f = -E/(R T) - and
@@ -888,7 +888,8 @@ class Lowered:
         root ("log", ("lin", coef) = exponent linear in 1/T with that coefficient, or "gen" = exponent stored),
         ``slot`` / ``fslot`` (cache slot of the value / of a "gen" exponent), ``slots`` (doubles per mesh node),
         ``branch`` (nodes evaluated inside the cached section, roots included), ``prologue`` (their root-free
-        T-only ancestors, evaluated before it)."""
+        T-only ancestors, evaluated before it).  ``gen=False`` leaves the "gen" constants (two slots each) out of the
+        cache: they are evaluated in full on either path (their log(T) still comes from the cache)."""
         g = self.g
         live = sorted(self.live)
 
@@ -901,27 +902,6 @@ class Lowered:
         for i in live:
             op, a, b = g.nodes[i]
             tonly[i] = True if op == "const" else ((a == "T") if op == "in" else all(tonly[o] for o in operands(i)))
-        roots = []
-        for i in live:
-            op, a, b = g.nodes[i]
-            if op in self._EXP_ROOTS and tonly[a] and not g.is_const(a):
-                roots.append(i)
-            elif op == "log" and g.nodes[a] == ("in", "T", None):
-                roots.append(i)
-        if not roots:
-            return None
-        rootset = set(roots)
-        dep = {}                      # depends on a root (strictly below it)
-        for i in live:
-            dep[i] = any(dep[o] or o in rootset for o in operands(i))
-        need, stack = set(), [g.nodes[r][1] for r in roots]
-        while stack:                  # ancestors of the roots' arguments
-            i = stack.pop()
-            if i in need:
-                continue
-            need.add(i)
-            stack.extend(operands(i))
-
         def lin_in_invT(i):
             """coefficient c if node i is exactly c/T through products with constants and negations, else None."""
             op, a, b = g.nodes[i]
@@ -939,6 +919,28 @@ class Lowered:
             if op == "div" and g.is_const(a) and g.nodes[b] == ("in", "T", None):
                 return g.cval(a)
             return None
+        roots = []
+        for i in live:
+            op, a, b = g.nodes[i]
+            if op in self._EXP_ROOTS and tonly[a] and not g.is_const(a):
+                if gen or lin_in_invT(a) not in (None, 0.0):
+                    roots.append(i)
+            elif op == "log" and g.nodes[a] == ("in", "T", None):
+                roots.append(i)
+        if not roots:
+            return None
+        rootset = set(roots)
+        dep = {}                      # depends on a root (strictly below it)
+        for i in live:
+            dep[i] = any(dep[o] or o in rootset for o in operands(i))
+        need, stack = set(), [g.nodes[r][1] for r in roots]
+        while stack:                  # ancestors of the roots' arguments
+            i = stack.pop()
+            if i in need:
+                continue
+            need.add(i)
+            stack.extend(operands(i))
+
         kind, slot, fslot, nslots = {}, {}, {}, 1          # slot 0: 1/T_ref
         for r in roots:
             op, a, b = g.nodes[r]
@@ -959,12 +961,17 @@ class Lowered:
         return {"roots": roots, "kind": kind, "slot": slot, "fslot": fslot, "slots": nslots, "branch": branch,
                 "prologue": prologue}
 
-    def emit(self, fname="rmt_kinetics", const_table=False, kcache=False):
+    def emit(self, fname="rmt_kinetics", const_table=False, kcache=False, kcache_gen=True, kcache_thr=None):
         """The device function of the rates.  ``kcache``: with the cached section of kcache_plan() for callers that
         pass a cache (template parameter KC with KC::enabled; every other caller passes rmt_nocache_t and gets the
         plain evaluation - the section is discarded at compile time)."""
         self._const_table = {} if const_table else None
-        plan = self.kcache_plan() if kcache else None
+        plan = self.kcache_plan(kcache_gen) if kcache else None
+        self._kc_thr = self.KC_THR
+        if kcache_thr is not None:        # (tests: a smaller range makes the callers' out-of-range handling run)
+            if not 0.0 < float(kcache_thr) <= self.KC_THR:
+                raise ValueError("the cache's Taylor range must lie in (0, 2^-9]")
+            self._kc_thr = float(kcache_thr)
         if plan is None:
             lines, name = self._emit_body()
         else:
@@ -1001,9 +1008,9 @@ class Lowered:
                for r in plan["roots"] if isinstance(plan["kind"][r], tuple)]
         tests = []
         if lin:
-            tests.append("!(rmt_abs(invT - it_) <= real(%r))" % (self.KC_THR/max(lin)))
+            tests.append("!(rmt_abs(invT - it_) <= real(%r))" % (self._kc_thr/max(lin)))
         if any(k == "log" for k in plan["kind"].values()):
-            tests.append("!(rmt_abs(T * it_ - real(1)) <= real(%r))" % self.KC_THR)
+            tests.append("!(rmt_abs(T * it_ - real(1)) <= real(%r))" % self._kc_thr)
         return ("template <typename KC>\n"
                 "__device__ __forceinline__ bool rmt_kinetics_stale(const real T, const real invT, const KC& kc) {\n"
                 "    (void)T; (void)invT;\n"
@@ -1030,14 +1037,26 @@ class Lowered:
                 done.add(i)
         for i in plan["branch"]:                          # values that leave the cached section
             lines.append("    real v%d;" % i)
-        thr = repr(self.KC_THR)
+        thr = repr(self._kc_thr)
         taylor = ("k_ + (k_ * d_) * (real(1) + d_ * (real(0.5) + d_ * (real(%r) + d_ * real(%r))))"
                   % (1.0/6.0, 1.0/24.0))
         L = lines.append
-        L("    if constexpr (KC::enabled && MODE == 1) {      // every constant from its cached value: K = K_ref e^d, d = f(T) - f(T_ref)")
+        L("    if constexpr (KC::enabled && MODE >= 1) {      // every constant from its cached value: K = K_ref e^d, d = f(T) - f(T_ref)")
         L("        const real kc_it = kc.get(0);")
         L("        const real kc_di = invT - kc_it;")
         L("        (void)kc_di;")
+        # MODE 2 has no second path: the range test of rmt_kinetics_stale sits here, next to the values it shares with the
+        # Taylor steps, and a lane out of range only marks its cache (the caller voids the step)
+        g_ = self.g
+        lin = [abs(self._EXP_ROOTS[g_.nodes[r][0]][0]*self._EXP_ROOTS[g_.nodes[r][0]][1]*plan["kind"][r][1])
+               for r in plan["roots"] if isinstance(plan["kind"][r], tuple)]
+        tests = []
+        if lin:
+            tests.append("!(rmt_abs(kc_di) <= real(%r))" % (self._kc_thr/max(lin)))
+        if any(k == "log" for k in plan["kind"].values()):
+            tests.append("!(rmt_abs(T * kc_it - real(1)) <= real(%r))" % self._kc_thr)
+        if tests:
+            L("        if constexpr (MODE == 2) kc.leave(%s);" % " || ".join(tests))
         for i in plan["branch"]:
             op, a, b = g.nodes[i]
             v = "v%d" % i
@@ -1063,7 +1082,8 @@ class Lowered:
                 sg, lnb = self._EXP_ROOTS[op]
                 L("        {")
                 L("            const real d_ = real(%r) * (%s - kc.get(%d));" % (sg*lnb, name[a], plan["fslot"][i]))
-                L("            if (KC::any(!(rmt_abs(d_) <= real(%s)))) {      // out of range in some lane: this constant in full," % thr)
+                L("            if constexpr (MODE == 2) kc.leave(!(rmt_abs(d_) <= real(%s)));    // no second path: the caller voids the step" % thr)
+                L("            if (MODE == 1 && KC::any(!(rmt_abs(d_) <= real(%s)))) {      // out of range in some lane: this constant in full," % thr)
                 name_i = dict(name)
                 for ln in emit(i, name_i, declare=False, nocheck=True):        # and its own reference point moves
                     L("            " + ln)
@@ -1075,18 +1095,18 @@ class Lowered:
                 L("            }")
                 L("        }")
             name[i] = v
-        L("    } else {                 // full evaluation; with a cache its reference point moves here")
+        L("    } else {                 // full evaluation; with a cache its reference point moves here (every constant is")
+        L("        if constexpr (KC::enabled) kc.put(0, invT);      // stored as soon as it exists: short live ranges)")
         for i in plan["branch"]:
             for ln in emit(i, name, declare=False):
                 L("    " + ln)
             done.add(i)
-        L("        if constexpr (KC::enabled) {")
-        L("            kc.put(0, invT);")
-        for r in plan["roots"]:
-            L("            kc.put(%d, v%d);" % (plan["slot"][r], r))
-            if r in plan["fslot"]:
-                L("            kc.put(%d, %s);" % (plan["fslot"][r], name[g.nodes[r][1]]))
-        L("        }")
+            if i in plan["slot"]:
+                L("        if constexpr (KC::enabled) {")
+                L("            kc.put(%d, v%d);" % (plan["slot"][i], i))
+                if i in plan["fslot"]:
+                    L("            kc.put(%d, %s);" % (plan["fslot"][i], name[g.nodes[i][1]]))
+                L("        }")
         L("    }")
         for i in sorted(self.live):
             if i not in done:

@@ -110,6 +110,23 @@ def rk45_geometry(V, N, fp32=False, chain=True, E=None):
     return block, npt, {"RMT_RK45_LDS": str(slots)}
 
 
+def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
+    """(defines, lds_state) with the on-chip RK4 stepper's cache of the temperature-only rate constants switched on where
+    it has been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body; profiles/round3_kcache.md): the 512 x 2 geometry
+    of a reactor of <= 1024 nodes, model N2 in fp64 - the bench shape, 1.62e10 -> 1.77e10 node-steps/s.  The cache holds
+    1/T_ref, log T_ref and the constants whose exponent is linear in 1/T (Arrhenius; RMT_KCACHE_GEN 0), y_n moves to LDS
+    (lds_state 1) to make room in the register file: with both the step loop has no spill.  An explicit "RMT_KCACHE" in
+    `defines` (0 or 1) or an lds_state other than 1 is left alone."""
+    defs = dict(defines or {})
+    if ("RMT_KCACHE" in defs or fp32 or getattr(mech, "model", "N2") != "N2" or (int(block), int(npt)) != (512, 2)
+            or int(N) > int(block)*int(npt) or lds_state not in (None, 1) or mech.V > 8):
+        return defs, lds_state
+    if not mech.kcache_fits(fp32, block, npt, 1, gen=False):
+        return defs, lds_state
+    defs.update({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0"})
+    return defs, 1
+
+
 def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=None, defines=None,
                   specialize=None, features=(), have_code=False):
     """What N2Device compiles for (mechanism, member rows, mesh): geometry, the prelude #defines (optional
@@ -121,7 +138,7 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
     E = members.shape[0]
     b, n = choose_geometry(int(N), mech.V, fp32, E)
     block, npt = int(block or b), int(npt or n)
-    defs = dict(defines or {})
+    defs, lds_state = kcache_choice(mech, N, fp32, block, npt, lds_state, defines)
     # optional kernel families: "ros4" (stiff stepper), "n1" (steady-state model); their
     # unrolled VxV linear algebra is most of the JIT time, so they are compiled on demand
     for f in features:
@@ -136,11 +153,10 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
         specialize = E >= 2
     if specialize:
         defs.update(plan.uniform_member_defines(members, mech.S))
-    # "RMT_KCACHE": "1" in `defines` (opt-in experiment, see lowering.Lowered.kcache_plan): the on-chip RK4 stepper
-    # caches the temperature-only rate constants per node in LDS.  Measured SLOWER on MI355X (1.28e10 vs 1.62e10
-    # node-steps/s on the bench shape, profiles/round3_kcache.md): the 512 x 2 kernel sits at exactly 256 VGPRs with no
-    # spill, the second code path costs 60 spilled VGPRs, and at two waves per SIMD every scratch access is exposed.
-    if str(defs.get("RMT_KCACHE", "0")) == "1" and not (int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state)):
+    # "RMT_KCACHE": "1" (kcache_choice above, or the caller's own): the on-chip RK4 stepper caches the temperature-only
+    # rate constants per node in LDS - that has to fit
+    if str(defs.get("RMT_KCACHE", "0")) == "1" and not (
+            int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state, str(defs.get("RMT_KCACHE_GEN", "1")) == "1")):
         raise ValueError("RMT_KCACHE=1: the cache of the temperature-only rate constants (%d doubles per node) does not "
                          "fit this geometry (needs the on-chip RK4 stepper with its vectors in registers, model N2, fp64)"
                          % mech.kcache_slots())
@@ -186,6 +202,7 @@ class N2Device:
         self.block, self.npt, self.defines, src, key = device_source(
             mech, members, self.N, self.fp32, block, npt, lds_state, defines, specialize, self.features,
             have_code=code is not None)
+        _, lds_state = kcache_choice(mech, self.N, self.fp32, self.block, self.npt, lds_state, defines)
         self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         if code is None:      # an ensemble rank may receive rank 0's code object instead
@@ -544,7 +561,7 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
     and broadcasts; pass the same E/block/npt/lds_state/defines to N2Device(code=...)."""
     b, n = choose_geometry(N, mech.V, fp32, E)
     block, npt = int(block or b), int(npt or n)
-    defines = dict(defines or {})
+    defines, lds_state = kcache_choice(mech, N, fp32, block, npt, lds_state, defines)
     tpl = hipbind.kernel_template()
     return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, lds_state, defines),
                                   mech.digest(tpl, fp32, block, npt, lds_state, defines), arch, extra_opts)

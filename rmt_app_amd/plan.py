@@ -247,19 +247,20 @@ class Mechanism:
             #                                              node-steps/s with 1 / 2 / 0 vectors in LDS)
         return fit
 
-    def kcache_slots(self):
+    def kcache_slots(self, gen=True):
         """doubles per mesh node the cache of the temperature-only rate constants needs (0: nothing to cache)."""
-        p = self.device_dag().kcache_plan()
+        p = self.device_dag().kcache_plan(gen)
         return p["slots"] if p else 0
 
-    def kcache_fits(self, fp32, block, npt, lds_state=None):
+    def kcache_fits(self, fp32, block, npt, lds_state=None, gen=True):
         """True when the on-chip RK4 stepper can keep that cache in LDS: model N2 in fp64, its RK4 vectors in
         registers (lds_state 0) and slots x nodes-per-workgroup doubles beside the exp table (16 KiB; 512 B for
         one-wave workgroups) and the exchange buffers within 150 KiB."""
-        slots = self.kcache_slots()
-        if not slots or fp32 or self.model != "N2" or self.lds_state(fp32, block, npt, lds_state) != 0:
+        slots = self.kcache_slots(gen)
+        if not slots or fp32 or self.model != "N2":
             return False
-        return slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
+        state = self.lds_state(fp32, block, npt, lds_state)*self.V*block*npt*8
+        return state + slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
 
     def kcache_fits_chain(self, fp32, block, npt, lds_state=None):
         """The same cache in the chained RK4 stepper (RMT_KCACHE_CHAIN): beside the chunk's RK4 vectors in LDS; worth it
@@ -276,7 +277,9 @@ class Mechanism:
             raise ValueError("kernel template lacks the RMT_KINETICS_SOURCE marker")
         kin = self.device_dag().emit("rmt_kinetics", const_table=bool((defines or {}).get("RMT_KINETICS_KTAB")),
                                      kcache=(str((defines or {}).get("RMT_KCACHE", "0")) == "1"
-                                             or str((defines or {}).get("RMT_KCACHE_CHAIN", "0")) == "1"))
+                                             or str((defines or {}).get("RMT_KCACHE_CHAIN", "0")) == "1"),
+                                     kcache_gen=str((defines or {}).get("RMT_KCACHE_GEN", "1")) == "1",
+                                     kcache_thr=(defines or {}).get("RMT_KCACHE_THR"))
         if (defines or {}).get("RMT_WITH_ROS4"):
             # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i
             kin += self.device_dag().gradient().emit_jac("rmt_kinetics_jac")

@@ -1,0 +1,104 @@
+"""GPU: the on-chip RK4 stepper with the temperature-only rate constants cached per node (csrc/kernels/50_rk4.inc
+rmt_rk4_reg_body<true>, chosen by n2.kcache_choice for the 512 x 2 geometry).  Stage 1 of a step evaluates the
+kinetics in full, stages 2-4 take K(T) = K(T_ref) e^d from the cache; a reactor whose stage temperatures leave the range
+that serves is integrated again by the plain stepper (rmt_n2_rk4_reg_redo).  Parity: against the oracle's RK4 (the
+reference's arithmetic, PyREMOT/core/pbHomoReactor.py:3706-4066 under solvers/odeSolver... RK4) and against the plain
+kernel; the redo path through a shrunken range (RMT_KCACHE_THR)."""
+import numpy as np
+import pytest
+
+import inputs as INP
+from oracle import n2_oracle as O
+from rmt_app_amd import plan
+from rmt_app_amd.lowering import FLAG_DOMAIN
+from rmt_app_amd.n2 import N2Device
+
+pytestmark = pytest.mark.gpu
+N = 1024
+
+
+def _sweep(E, hot=0.0):
+    mech = plan.Mechanism(INP.dme_notebook_input())
+    rows, named, inputs = [], [], []
+    for e in range(E):
+        mi = INP.dme_notebook_input()
+        mi["operating-conditions"]["temperature"] = 513.0 + 4.0*e + hot*(e % 2)
+        nm, row = plan.member_constants(mi, mech, N)
+        rows.append(row), named.append(nm), inputs.append(mi)
+    return mech, np.array(rows), np.array([plan.initial_state(nm, mech, N) for nm in named]), inputs
+
+
+def _run(mech, rows, IV, steps, dt=2e-6, **kw):
+    dev = N2Device(mech, rows, N, block=512, npt=2, **kw)
+    y = dev.to_device(IV)
+    dev.rk4(y, dt, steps)
+    out, flags = y.cpu().numpy(), dev.status().copy()
+    info = (dict(dev.defines), dev.lds_state)
+    dev.close()
+    return out, flags, info
+
+
+def test_cached_stepper_is_the_default_at_512x2_and_matches_plain_and_oracle():
+    mech, rows, IV, inputs = _sweep(6)
+    got, flags, (defs, lds) = _run(mech, rows, IV, 300)
+    assert defs.get("RMT_KCACHE") == "1" and defs.get("RMT_KCACHE_GEN") == "0" and lds == 1
+    assert not flags.any()
+    plain, pflags, (pdefs, plds) = _run(mech, rows, IV, 300, defines={"RMT_KCACHE": "0"})
+    assert pdefs["RMT_KCACHE"] == "0" and plds == 0 and not pflags.any()
+    scale = np.max(np.abs(plain.reshape(6, 7, N)), axis=2, keepdims=True)
+    assert np.max(np.abs(got - plain).reshape(6, 7, N)/scale) < 2e-13
+    for e in (0, 5):
+        pr = O.setup_n2(inputs[e], N)
+        want = O.rk4(0.0, 60*2e-6, 60, pr["IV"], O.make_rhs_vec(pr), keep=False)
+        g60, f60, _ = _run(mech, rows[e:e + 1], IV[e:e + 1], 60)
+        sc = np.max(np.abs(want.reshape(7, N)), axis=1, keepdims=True)
+        assert not f60.any()
+        assert np.max(np.abs(g60[0].reshape(7, N) - want.reshape(7, N))/sc) < 1e-11, e
+
+
+@pytest.mark.parametrize("thr", ["1e-12", "3e-7", "2e-5"])
+def test_reactors_that_leave_the_cache_range_are_integrated_again_in_full(thr):
+    """A shrunken Taylor range (1e-12: every stage of every reactor is out of range; the others: some) - the voided
+    reactors come back from the plain stepper of the same code object, bit for bit what a cache-less build of the same
+    geometry gives, and no internal flag bit is left behind."""
+    mech, rows, IV, _ = _sweep(8, hot=25.0)
+    got, flags, (defs, lds) = _run(mech, rows, IV, 150, defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0",
+                                                                   "RMT_KCACHE_THR": thr}, lds_state=1)
+    assert defs["RMT_KCACHE_THR"] == thr and lds == 1
+    assert not flags.any(), flags
+    plain, pflags, _ = _run(mech, rows, IV, 150, defines={"RMT_KCACHE": "0"}, lds_state=1)
+    assert not pflags.any()
+    if thr == "1e-12":
+        np.testing.assert_array_equal(got, plain)
+    else:
+        scale = np.max(np.abs(plain.reshape(8, 7, N)), axis=2, keepdims=True)
+        assert np.max(np.abs(got - plain).reshape(8, 7, N)/scale) < 2e-13
+
+
+def test_second_launch_continues_a_redone_reactor_and_a_cached_one_alike():
+    """Two launches back to back equal one of twice the length (the state in memory after a voided launch is the plain
+    stepper's; the flag word carries nothing over)."""
+    mech, rows, IV, _ = _sweep(4, hot=25.0)
+    kw = dict(defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0", "RMT_KCACHE_THR": "3e-7"}, lds_state=1)
+    dev = N2Device(mech, rows, N, block=512, npt=2, **kw)
+    y = dev.to_device(IV)
+    dev.rk4(y, 2e-6, 80)
+    dev.rk4(y, 2e-6, 80)
+    assert not dev.status().any()
+    two = y.cpu().numpy()
+    dev.close()
+    one, flags, _ = _run(mech, rows, IV, 160, **kw)
+    assert not flags.any()
+    scale = np.max(np.abs(one.reshape(4, 7, N)), axis=2, keepdims=True)
+    assert np.max(np.abs(two - one).reshape(4, 7, N)/scale) < 2e-13
+
+
+def test_python_exception_flags_survive_the_cached_stepper():
+    """A negative absolute temperature at one node of one reactor (theta = -1.5): log(T) in the equilibrium constants -
+    Python's ValueError, RMT_N2_FLAG_DOMAIN on that reactor and on no other (stage 1 is the tested, full evaluation)."""
+    mech, rows, IV, _ = _sweep(3)
+    IV = IV.copy()
+    IV[1].reshape(7, N)[6, 300] = -1.5
+    _, flags, (defs, _) = _run(mech, rows, IV, 2)
+    assert defs.get("RMT_KCACHE") == "1"
+    assert flags[1] & FLAG_DOMAIN and not flags[0] and not flags[2]

@@ -662,7 +662,7 @@ def test_ensemble_output_outlet_keeps_only_the_last_node():
         run(**{"ensemble-output": "everything"})
 
 
-# ----------------------------------------------------------------------------- K-cache (opt-in experiment)
+# ----------------------------------------------------------------------------- cache of the temperature-only rate constants
 def test_kcache_plan_and_emission_for_the_test_mechanisms(template):
     """lowering.Lowered.kcache_plan: the temperature-only exp / log roots of every test mechanism, their cache slots,
     and the generated source with the cached section still builds for the host (where the section is discarded) and
@@ -688,6 +688,34 @@ def test_kcache_plan_and_emission_for_the_test_mechanisms(template):
     with pytest.raises(ValueError):                        # the 12-species geometry keeps its RK4 vectors in LDS: no room
         device_source(syn, row if False else plan.member_constants(INP.syn12_input(), syn, 1024)[1], 1024,
                       defines={"RMT_KCACHE": "1"})
+
+
+def test_kcache_choice_and_the_code_object_it_builds():
+    """n2.kcache_choice: the cache is switched on for the measured geometry only (512 x 2, model N2, fp64, a reactor that
+    fits the workgroup), with y_n in LDS; an explicit RMT_KCACHE or another lds_state is left alone.  The code object then
+    carries the plain stepper as rmt_n2_rk4_reg_redo and its cached step loop has no scratch access."""
+    from rmt_app_amd import hipbind, isa
+    from rmt_app_amd.n2 import device_source, kcache_choice
+    dme = plan.Mechanism(INP.dme_notebook_input())
+    on = ({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0"}, 1)
+    assert kcache_choice(dme, 1024, False, 512, 2, None, None) == on
+    assert kcache_choice(dme, 1000, False, 512, 2, 1, {"X": "1"}) == (dict(on[0], X="1"), 1)
+    assert kcache_choice(dme, 1024, False, 512, 2, 0, None) == ({}, 0)                  # the caller's lds_state wins
+    assert kcache_choice(dme, 1024, False, 512, 2, None, {"RMT_KCACHE": "0"}) == ({"RMT_KCACHE": "0"}, None)
+    assert kcache_choice(dme, 1024, True, 512, 2, None, None) == ({}, None)             # fp32
+    assert kcache_choice(dme, 4096, False, 512, 2, None, None) == ({}, None)            # chained reactor
+    assert kcache_choice(dme, 1024, False, 256, 1, None, None) == ({}, None)            # other geometries: not measured
+    assert kcache_choice(plan.Mechanism(INP.ch4_input()), 1024, False, 512, 2, None, None) == ({}, None)   # nothing to cache
+    assert kcache_choice(plan.Mechanism(INP.m2_dme_input()), 1024, False, 512, 2, None, None) == ({}, None)
+    _, row = plan.member_constants(INP.dme_notebook_input(), dme, 1024)
+    block, npt, defs, src, key = device_source(dme, np.tile(row, (256, 1)), 1024)
+    assert (block, npt) == (512, 2) and defs["RMT_KCACHE"] == "1" and "#define RMT_LDS_STATE 1" in src
+    blob = hipbind.compile_cached(src, key, "gfx950")
+    st = isa.kernel_stats(blob, "rmt_n2_rk4_reg")
+    assert st["step_loop"]["scratch"] == 0 and st["step_loop"]["valu"] < 3400           # (the plain stepper: 3689)
+    assert isa.kernel_stats(blob, "rmt_n2_rk4_reg_redo")["whole"]["valu"] > 3000        # the plain stepper, same object
+    with pytest.raises(ValueError):
+        dme.source(hipbind.kernel_template(), defines={"RMT_KCACHE": "1", "RMT_KCACHE_THR": "0.5"})
 
 
 # ----------------------------------------------------------------------------- stiff stepper, quad layout (V > 8)

@@ -48,7 +48,7 @@ struct rmt_n2_handle {
     hipModule_t module = nullptr;
     hipFunction_t f_rhs = nullptr, f_rk4_reg = nullptr, f_rk4_mem = nullptr, f_rk45_reg = nullptr,
                   f_rk45_mem = nullptr, f_multistep = nullptr, f_rk4_chain = nullptr, f_ros4 = nullptr, f_n1 = nullptr,
-                  f_ros4_chain = nullptr, f_rk45_chain = nullptr, f_rk4_redo = nullptr;
+                  f_ros4_chain = nullptr, f_rk45_chain = nullptr, f_rk4_redo = nullptr, f_rk4_chain_redo = nullptr;
     unsigned long long* d_rings = nullptr;   // tagged-word links of the chained stiff stepper: rings, decision slots, abort words
     size_t ring_bytes = 0;
     double* d_members1 = nullptr;
@@ -61,6 +61,8 @@ struct rmt_n2_handle {
     double* d_members = nullptr;
     unsigned* d_flags = nullptr;
     void* d_work = nullptr;
+    void* d_backup = nullptr;          // chained cached RK4 stepper: the launch's input, and its redo / status words
+    unsigned* d_redo = nullptr;
     size_t work_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -220,6 +222,8 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
         h->f_multistep = nullptr;
     if (hipModuleGetFunction(&h->f_rk4_chain, h->module, "rmt_n2_rk4_chain") != hipSuccess)
         h->f_rk4_chain = nullptr;
+    if (hipModuleGetFunction(&h->f_rk4_chain_redo, h->module, "rmt_n2_rk4_chain_redo") != hipSuccess)
+        h->f_rk4_chain_redo = nullptr;
     if (hipModuleGetFunction(&h->f_ros4, h->module, "rmt_n2_ros4_mem") != hipSuccess)
         h->f_ros4 = nullptr;
     if (hipModuleGetFunction(&h->f_n1, h->module, "rmt_n1_ros4") != hipSuccess) h->f_n1 = nullptr;
@@ -244,6 +248,8 @@ extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (h->d_members) (void)hipFree(h->d_members);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_backup) (void)hipFree(h->d_backup);
+    if (h->d_redo) (void)hipFree(h->d_redo);
     if (h->d_mask) (void)hipFree(h->d_mask);
     if (h->d_members1) (void)hipFree(h->d_members1);
     if (h->d_sync) (void)hipFree(h->d_sync);
@@ -391,14 +397,38 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
             HIP_OK(hipMalloc((void**)&h->d_slots, links * 8 * (size_t)(h->V + 1) * sizeof(double)));
             h->chain_links = links;
         }
-        HIP_OK(hipMemsetAsync(h->d_sync, 0, links * 32 * sizeof(unsigned long long), h->stream));
+        // a chained stepper that caches the temperature-only rate constants (RMT_KCACHE_CHAIN) saves the launch's input
+        // and is followed by rmt_n2_rk4_chain_redo on the same grid, see kernels/50_rk4.inc rmt_rk4_chain_body
+        void* backup = nullptr;
+        unsigned *redo = nullptr, *falt = nullptr;
+        if (h->f_rk4_chain_redo) {
+            const size_t state = (size_t)h->E * h->V * h->N * (h->fp32 ? 4 : 8);
+            if (!h->d_backup) {
+                HIP_OK(hipMalloc(&h->d_backup, state));
+                HIP_OK(hipMalloc((void**)&h->d_redo, 2 * (size_t)h->E * sizeof(unsigned)));
+            }
+            backup = h->d_backup;
+            redo = h->d_redo;
+            falt = h->d_redo + h->E;
+            HIP_OK(hipMemsetAsync(h->d_redo, 0, 2 * (size_t)h->E * sizeof(unsigned), h->stream));
+        }
         unsigned long long* decision = nullptr;
         unsigned* abort_words = nullptr;
-        if (ensure_rings(h, T, C, &decision, &abort_words)) return 1;
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
                         (void*)&dt, (void*)&ns, (void*)&h->d_sync, (void*)&h->d_slots, (void*)&h->d_flags,
-                        (void*)&h->d_rings, (void*)&abort_words};
-        return launch(h, h->f_rk4_chain, args, T * C, C, T);
+                        (void*)&h->d_rings, (void*)&abort_words, (void*)&backup, (void*)&redo, (void*)&falt};
+        h->last_chunks = C;
+        h->last_teams = T;
+        HIP_OK(hipEventRecord(h->ev0, h->stream));
+        for (hipFunction_t f : {h->f_rk4_chain, h->f_rk4_chain_redo}) {
+            if (!f) continue;
+            HIP_OK(hipMemsetAsync(h->d_sync, 0, links * 32 * sizeof(unsigned long long), h->stream));
+            if (ensure_rings(h, T, C, &decision, &abort_words)) return 1;        // (clears the rings)
+            HIP_OK(hipModuleLaunchKernel(f, (unsigned)(T * C), 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args, nullptr));
+        }
+        HIP_OK(hipEventRecord(h->ev1, h->stream));
+        h->timed = true;
+        return 0;
     }
     if (ensure_work(h, 3)) return 1;
     void* args[] = {(void*)&y, (void*)&h->d_work, (void*)&h->d_members, (void*)&N, (void*)&E,

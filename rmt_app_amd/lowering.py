@@ -987,8 +987,7 @@ class Lowered:
             self._table_decl = ""
         outs = "\n".join("    r[%d] = %s;" % (k, name[o]) for k, o in enumerate(self.outputs))
         head = "#define RMT_KC_SLOTS %d\n" % (plan["slots"] if plan else 0)
-        stale = self._emit_stale(plan)
-        return head + self._table_decl + stale + (
+        return head + self._table_decl + (
             "template <typename FL, typename KC, int MODE = 0>\n"
             "__device__ __forceinline__ void %s(const real T, const real invT, const real P,\n"
             "        const real* __restrict__ x, const real* __restrict__ C, const real* __restrict__ U,\n"
@@ -996,34 +995,12 @@ class Lowered:
             "    (void)invT; (void)U; (void)kc;\n%s\n%s\n}\n"
             % (fname, body, outs))
 
-    def _emit_stale(self, plan):
-        """rmt_kinetics_stale(T, 1/T, cache): true when this node's cache cannot serve the state - not filled yet, or
-        T so far from the reference point that an exponent LINEAR in 1/T (Arrhenius) or log(T) leaves the Taylor range.
-        The caller ORs it over the wave and picks MODE 0 (full evaluation, moves the reference point) or MODE 1."""
-        if plan is None:
-            return ("template <typename KC>\n__device__ __forceinline__ bool rmt_kinetics_stale(const real, const real, "
-                    "const KC&) { return false; }\n")
-        g = self.g
-        lin = [abs(self._EXP_ROOTS[g.nodes[r][0]][0]*self._EXP_ROOTS[g.nodes[r][0]][1]*plan["kind"][r][1])
-               for r in plan["roots"] if isinstance(plan["kind"][r], tuple)]
-        tests = []
-        if lin:
-            tests.append("!(rmt_abs(invT - it_) <= real(%r))" % (self._kc_thr/max(lin)))
-        if any(k == "log" for k in plan["kind"].values()):
-            tests.append("!(rmt_abs(T * it_ - real(1)) <= real(%r))" % self._kc_thr)
-        return ("template <typename KC>\n"
-                "__device__ __forceinline__ bool rmt_kinetics_stale(const real T, const real invT, const KC& kc) {\n"
-                "    (void)T; (void)invT;\n"
-                "    if (!kc.valid) return true;\n"
-                "    const real it_ = kc.get(0);\n"
-                "    (void)it_;\n"
-                "    return %s;\n}\n" % (" || ".join(tests) if tests else "false"))
-
     def _emit_cached(self, plan):
-        """Body with the cached section: MODE 1 (the caller has checked rmt_kinetics_stale for the whole wave) takes every
-        cached constant from its reference value by a Taylor step - exponents that are not linear in 1/T test their own
-        |d| and, when a lane of the wave is out of range, are evaluated in full and move their own reference point;
-        MODE 0 evaluates in full and (with a cache) stores the new reference point."""
+        """Body with the cached section: MODE 2 takes every cached constant from its reference value by a Taylor step
+        and tests the range that step serves - |d| <= KC_THR in every exponent, |T/T_ref - 1| <= KC_THR for log(T) - a
+        lane out of range only marks its cache (`kc.leave`: there is no second code path, the CALLER discards what it
+        computed from such an evaluation, see csrc/kernels/50_rk4.inc rmt_rk4_reg_body); MODE 0 evaluates in full and
+        (with a cache) stores the new reference point."""
         g = self.g
         emit = self._emitter()
         lines, name = [], {}
@@ -1041,12 +1018,11 @@ class Lowered:
         taylor = ("k_ + (k_ * d_) * (real(1) + d_ * (real(0.5) + d_ * (real(%r) + d_ * real(%r))))"
                   % (1.0/6.0, 1.0/24.0))
         L = lines.append
-        L("    if constexpr (KC::enabled && MODE >= 1) {      // every constant from its cached value: K = K_ref e^d, d = f(T) - f(T_ref)")
+        L("    if constexpr (KC::enabled && MODE == 2) {      // every constant from its cached value: K = K_ref e^d, d = f(T) - f(T_ref)")
         L("        const real kc_it = kc.get(0);")
         L("        const real kc_di = invT - kc_it;")
         L("        (void)kc_di;")
-        # MODE 2 has no second path: the range test of rmt_kinetics_stale sits here, next to the values it shares with the
-        # Taylor steps, and a lane out of range only marks its cache (the caller voids the step)
+        # the range test sits next to the values it shares with the Taylor steps
         g_ = self.g
         lin = [abs(self._EXP_ROOTS[g_.nodes[r][0]][0]*self._EXP_ROOTS[g_.nodes[r][0]][1]*plan["kind"][r][1])
                for r in plan["roots"] if isinstance(plan["kind"][r], tuple)]
@@ -1056,7 +1032,7 @@ class Lowered:
         if any(k == "log" for k in plan["kind"].values()):
             tests.append("!(rmt_abs(T * kc_it - real(1)) <= real(%r))" % self._kc_thr)
         if tests:
-            L("        if constexpr (MODE == 2) kc.leave(%s);" % " || ".join(tests))
+            L("        kc.leave(%s);" % " || ".join(tests))
         for i in plan["branch"]:
             op, a, b = g.nodes[i]
             v = "v%d" % i
@@ -1082,17 +1058,9 @@ class Lowered:
                 sg, lnb = self._EXP_ROOTS[op]
                 L("        {")
                 L("            const real d_ = real(%r) * (%s - kc.get(%d));" % (sg*lnb, name[a], plan["fslot"][i]))
-                L("            if constexpr (MODE == 2) kc.leave(!(rmt_abs(d_) <= real(%s)));    // no second path: the caller voids the step" % thr)
-                L("            if (MODE == 1 && KC::any(!(rmt_abs(d_) <= real(%s)))) {      // out of range in some lane: this constant in full," % thr)
-                name_i = dict(name)
-                for ln in emit(i, name_i, declare=False, nocheck=True):        # and its own reference point moves
-                    L("            " + ln)
-                L("                kc.put(%d, %s);" % (plan["slot"][i], v))
-                L("                kc.put(%d, %s);" % (plan["fslot"][i], name[a]))
-                L("            } else {")
-                L("                const real k_ = kc.get(%d);" % plan["slot"][i])
-                L("                %s = %s;" % (v, taylor))
-                L("            }")
+                L("            kc.leave(!(rmt_abs(d_) <= real(%s)));" % thr)
+                L("            const real k_ = kc.get(%d);" % plan["slot"][i])
+                L("            %s = %s;" % (v, taylor))
                 L("        }")
             name[i] = v
         L("    } else {                 // full evaluation; with a cache its reference point moves here (every constant is")

@@ -113,17 +113,21 @@ def rk45_geometry(V, N, fp32=False, chain=True, E=None):
 def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     """(defines, lds_state) with the on-chip RK4 stepper's cache of the temperature-only rate constants switched on where
     it has been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body; profiles/round3_kcache.md): the 512 x 2 geometry
-    of a reactor of <= 1024 nodes, model N2 in fp64 - the bench shape, 1.62e10 -> 1.77e10 node-steps/s.  The cache holds
+    of model N2 in fp64 - one workgroup per reactor (RMT_KCACHE; the bench shape, 1.62e10 -> 1.81e10 node-steps/s) or
+    chained workgroups (RMT_KCACHE_CHAIN; reactors beyond 1024 nodes in ensembles that fill the chip).  The cache holds
     1/T_ref, log T_ref and the constants whose exponent is linear in 1/T (Arrhenius; RMT_KCACHE_GEN 0), y_n moves to LDS
     (lds_state 1) to make room in the register file: with both the step loop has no spill.  An explicit "RMT_KCACHE" in
     `defines` (0 or 1) or an lds_state other than 1 is left alone."""
     defs = dict(defines or {})
-    if ("RMT_KCACHE" in defs or fp32 or getattr(mech, "model", "N2") != "N2" or (int(block), int(npt)) != (512, 2)
-            or int(N) > int(block)*int(npt) or lds_state not in (None, 1) or mech.V > 8):
+    chained = int(N) > int(block)*int(npt)
+    key = "RMT_KCACHE_CHAIN" if chained else "RMT_KCACHE"
+    if (key in defs or fp32 or getattr(mech, "model", "N2") != "N2" or (int(block), int(npt)) != (512, 2)
+            or lds_state not in (None, 1) or mech.V > 8):
         return defs, lds_state
-    if not mech.kcache_fits(fp32, block, npt, 1, gen=False):
+    fits = mech.kcache_fits_chain if chained else mech.kcache_fits
+    if not fits(fp32, block, npt, 1, gen=False):
         return defs, lds_state
-    defs.update({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0"})
+    defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
     return defs, 1
 
 
@@ -155,8 +159,12 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
         defs.update(plan.uniform_member_defines(members, mech.S))
     # "RMT_KCACHE": "1" (kcache_choice above, or the caller's own): the on-chip RK4 stepper caches the temperature-only
     # rate constants per node in LDS - that has to fit
+    gen = str(defs.get("RMT_KCACHE_GEN", "1")) == "1"
+    if str(defs.get("RMT_KCACHE_CHAIN", "0")) == "1" and not mech.kcache_fits_chain(fp32, block, npt, lds_state, gen):
+        raise ValueError("RMT_KCACHE_CHAIN=1: the cache of the temperature-only rate constants (%d doubles per node) does "
+                         "not fit beside the chunk's RK4 vectors (model N2, fp64)" % mech.kcache_slots(gen))
     if str(defs.get("RMT_KCACHE", "0")) == "1" and not (
-            int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state, str(defs.get("RMT_KCACHE_GEN", "1")) == "1")):
+            int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state, gen)):
         raise ValueError("RMT_KCACHE=1: the cache of the temperature-only rate constants (%d doubles per node) does not "
                          "fit this geometry (needs the on-chip RK4 stepper with its vectors in registers, model N2, fp64)"
                          % mech.kcache_slots())

@@ -262,11 +262,10 @@ class Mechanism:
         state = self.lds_state(fp32, block, npt, lds_state)*self.V*block*npt*8
         return state + slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
 
-    def kcache_fits_chain(self, fp32, block, npt, lds_state=None):
-        """The same cache in the chained RK4 stepper (RMT_KCACHE_CHAIN): beside the chunk's RK4 vectors in LDS; worth it
-        where a stage is latency-bound - one node per lane, small chunks (one wave per SIMD, registers to spare)."""
-        slots = self.kcache_slots()
-        if not slots or fp32 or self.model != "N2" or npt != 1 or block > 256:
+    def kcache_fits_chain(self, fp32, block, npt, lds_state=None, gen=True):
+        """The same cache in the chained RK4 stepper (RMT_KCACHE_CHAIN): beside the chunk's RK4 vectors in LDS."""
+        slots = self.kcache_slots(gen)
+        if not slots or fp32 or self.model != "N2":
             return False
         state = self.lds_state(fp32, block, npt, lds_state, chained=True)*self.V*block*npt*8
         return state + slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024

@@ -102,3 +102,76 @@ def test_python_exception_flags_survive_the_cached_stepper():
     _, flags, (defs, _) = _run(mech, rows, IV, 2)
     assert defs.get("RMT_KCACHE") == "1"
     assert flags[1] & FLAG_DOMAIN and not flags[0] and not flags[2]
+
+
+# ----------------------------------------------------------------------------- the chained stepper (reactors beyond 1024 nodes)
+NC = 2500            # three chunks of 1024 nodes, the last one ragged
+
+
+def _chain_sweep(E, hot=0.0):
+    mech = plan.Mechanism(INP.dme_notebook_input())
+    rows, named, inputs = [], [], []
+    for e in range(E):
+        mi = INP.dme_notebook_input()
+        mi["operating-conditions"]["temperature"] = 513.0 + 30.0*e/max(E - 1, 1) + hot*(e % 2)
+        nm, row = plan.member_constants(mi, mech, NC)
+        rows.append(row), named.append(nm), inputs.append(mi)
+    return mech, np.array(rows), np.array([plan.initial_state(nm, mech, NC) for nm in named]), inputs
+
+
+def _run_chain(mech, rows, IV, steps, **kw):
+    dev = N2Device(mech, rows, NC, block=512, npt=2, **kw)
+    dev.set_mode("chain")
+    y = dev.to_device(IV)
+    dev.rk4(y, 2e-6, steps)
+    out, flags, info = y.cpu().numpy(), dev.status().copy(), (dict(dev.defines), dev.lds_state, dev.last_geometry())
+    dev.close()
+    return out, flags, info
+
+
+def test_chained_cached_stepper_matches_plain_chain_and_oracle():
+    E = 5
+    mech, rows, IV, inputs = _chain_sweep(E)
+    got, flags, (defs, lds, geo) = _run_chain(mech, rows, IV, 120)
+    assert defs.get("RMT_KCACHE_CHAIN") == "1" and lds == 1 and geo[0] == 3
+    assert not flags.any()
+    plain, pflags, (pdefs, _, _) = _run_chain(mech, rows, IV, 120, defines={"RMT_KCACHE_CHAIN": "0"})
+    assert pdefs["RMT_KCACHE_CHAIN"] == "0" and not pflags.any()
+    scale = np.max(np.abs(plain.reshape(E, 7, NC)), axis=2, keepdims=True)
+    assert np.max(np.abs(got - plain).reshape(E, 7, NC)/scale) < 2e-13
+    pr = O.setup_n2(inputs[E - 1], NC)
+    want = O.rk4(0.0, 120*2e-6, 120, pr["IV"], O.make_rhs_vec(pr), keep=False)
+    sc = np.max(np.abs(want.reshape(7, NC)), axis=1, keepdims=True)
+    assert np.max(np.abs(got[E - 1].reshape(7, NC) - want.reshape(7, NC))/sc) < 1e-11
+
+
+@pytest.mark.parametrize("thr", ["1e-12", "3e-7"])
+def test_chained_reactors_that_leave_the_cache_range_are_integrated_again(thr):
+    """More reactors than teams, so a team meets voided and clean reactors in one launch; the voided ones are integrated
+    again from the saved input by rmt_n2_rk4_chain_redo (1e-12: all of them = the plain chained build bit for bit)."""
+    E = 200                                # 85 teams of three chunks on 256 CUs: two or three reactors per team
+    mech, rows, IV, _ = _chain_sweep(E, hot=20.0)
+    kw = dict(defines={"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0", "RMT_KCACHE_THR": thr}, lds_state=1)
+    got, flags, (_, _, geo) = _run_chain(mech, rows, IV, 40, **kw)
+    assert geo[0] == 3 and geo[1] < E
+    assert not flags.any(), flags[flags != 0][:4]
+    plain, pflags, _ = _run_chain(mech, rows, IV, 40, defines={"RMT_KCACHE_CHAIN": "0"}, lds_state=1)
+    assert not pflags.any()
+    if thr == "1e-12":
+        np.testing.assert_array_equal(got, plain)
+    else:
+        scale = np.max(np.abs(plain.reshape(E, 7, NC)), axis=2, keepdims=True)
+        assert np.max(np.abs(got - plain).reshape(E, 7, NC)/scale) < 2e-13
+
+
+def test_chained_cached_stepper_reports_python_exceptions_of_clean_and_redone_reactors():
+    """Status bits travel through the side word of the cached kernel (merged by the redo kernel): a negative absolute
+    temperature in reactor 1 (clean path) and in reactor 2 of a build whose range voids everything."""
+    mech, rows, IV, _ = _chain_sweep(4)
+    IV = IV.copy()
+    IV[1].reshape(7, NC)[6, 1800] = -1.5
+    _, flags, _ = _run_chain(mech, rows, IV, 2)
+    assert flags[1] & FLAG_DOMAIN and not flags[0] and not flags[2] and not flags[3]
+    _, flags, _ = _run_chain(mech, rows, IV, 2, defines={"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0",
+                                                          "RMT_KCACHE_THR": "1e-12"}, lds_state=1)
+    assert flags[1] & FLAG_DOMAIN and not flags[0] and not flags[2] and not flags[3]

@@ -676,7 +676,7 @@ def test_kcache_plan_and_emission_for_the_test_mechanisms(template):
     assert syn.kcache_slots() == 9                         # 1/T_ref + eight Arrhenius constants
     assert plan.Mechanism(INP.ch4_input()).kcache_slots() == 0
     src = dme.source(template, defines={"RMT_KCACHE": "1"})
-    assert "rmt_kinetics_stale" in src and "#define RMT_KC_SLOTS 14" in src and "MODE == 1" in src
+    assert "#define RMT_KC_SLOTS 14" in src and "MODE == 2" in src and "kc.leave(" in src
     g = np.load(os.path.join(G, "g2_rhs.npz"))
     Y, F = g["dme_nb_20_y"], g["dme_nb_20_f"]
     _, row = plan.member_constants(INP.dme_notebook_input(), dme, 20)
@@ -703,7 +703,10 @@ def test_kcache_choice_and_the_code_object_it_builds():
     assert kcache_choice(dme, 1024, False, 512, 2, 0, None) == ({}, 0)                  # the caller's lds_state wins
     assert kcache_choice(dme, 1024, False, 512, 2, None, {"RMT_KCACHE": "0"}) == ({"RMT_KCACHE": "0"}, None)
     assert kcache_choice(dme, 1024, True, 512, 2, None, None) == ({}, None)             # fp32
-    assert kcache_choice(dme, 4096, False, 512, 2, None, None) == ({}, None)            # chained reactor
+    chain = ({"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0"}, 1)
+    assert kcache_choice(dme, 4096, False, 512, 2, None, None) == chain                 # chained reactor: the chunks' cache
+    assert kcache_choice(dme, 4096, False, 512, 2, None, {"RMT_KCACHE_CHAIN": "0"}) == ({"RMT_KCACHE_CHAIN": "0"}, None)
+    assert kcache_choice(dme, 4096, False, 128, 1, None, None) == ({}, None)
     assert kcache_choice(dme, 1024, False, 256, 1, None, None) == ({}, None)            # other geometries: not measured
     assert kcache_choice(plan.Mechanism(INP.ch4_input()), 1024, False, 512, 2, None, None) == ({}, None)   # nothing to cache
     assert kcache_choice(plan.Mechanism(INP.m2_dme_input()), 1024, False, 512, 2, None, None) == ({}, None)
@@ -714,6 +717,12 @@ def test_kcache_choice_and_the_code_object_it_builds():
     st = isa.kernel_stats(blob, "rmt_n2_rk4_reg")
     assert st["step_loop"]["scratch"] == 0 and st["step_loop"]["valu"] < 3400           # (the plain stepper: 3689)
     assert isa.kernel_stats(blob, "rmt_n2_rk4_reg_redo")["whole"]["valu"] > 3000        # the plain stepper, same object
+    _, row4 = plan.member_constants(INP.dme_notebook_input(), dme, 4096)
+    block, npt, defs, src, key = device_source(dme, np.tile(row4, (256, 1)), 4096)
+    assert (block, npt) == (512, 2) and defs["RMT_KCACHE_CHAIN"] == "1" and "#define RMT_LDS_STATE_CHAIN 1" in src
+    blob = hipbind.compile_cached(src, key, "gfx950")
+    assert isa.kernel_stats(blob, "rmt_n2_rk4_chain")["step_loop"]["scratch"] == 0
+    assert isa.kernel_stats(blob, "rmt_n2_rk4_chain_redo")["whole"]["valu"] > 3000
     with pytest.raises(ValueError):
         dme.source(hipbind.kernel_template(), defines={"RMT_KCACHE": "1", "RMT_KCACHE_THR": "0.5"})
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One launch of one stepper on one shape (for rocprofv3):
    run_one.py <rk4|rk45|ros4> <mechanism> <N> <E> <t1-or-steps> [block] [npt] [mode] [NAME=VAL ...]
-   COPT="<hipRTC options>", RTOL=<rtol> and SPECIALIZE=0|1 are taken out of the NAME=VAL list (not kernel macros)."""
+   COPT="<hipRTC options>", RTOL=<rtol>, SPECIALIZE=0|1 and LDS=0|1|2 are taken out of the NAME=VAL list (not kernel macros)."""
 import os
 import sys
 
@@ -20,6 +20,7 @@ defines = dict(a.split("=", 1) for a in sys.argv[6:] if "=" in a)
 copt = defines.pop("COPT", "")
 rtol = float(defines.pop("RTOL", 1e-6))
 spec = defines.pop("SPECIALIZE", None)          # 0 / 1: member fields as run-time values / literals (default: n2's rule)
+lds = defines.pop("LDS", None)                  # RK4 vectors kept in LDS (0, 1, 2; default: plan.Mechanism.lds_state)
 block = int(pos[0]) if len(pos) > 0 and pos[0] != "-" else None
 npt = int(pos[1]) if len(pos) > 1 and pos[1] != "-" else None
 mode = pos[2] if len(pos) > 2 else "auto"
@@ -27,6 +28,7 @@ mi = INP.ALL_N2_INPUTS[name]()
 mech = plan.Mechanism(mi)
 nm, row = plan.member_constants(mi, mech, N)
 dev = N2Device(mech, np.tile(row, (E, 1)), N, block=block, npt=npt, defines=defines, extra_opts=copt,
+               lds_state=None if lds is None else int(lds),
                specialize=None if spec is None else bool(int(spec)),
                features=("ros4",) if step == "ros4" else ())
 dev.set_mode(mode)

@@ -374,6 +374,25 @@ def stiff_wide_mechanism():
                 "chain" if geo[0] > 1 else "mem", geo[0], geo[1]), "flags_ok": bool(ok)}
 
 
+def executed_step_mix(loop, kname, dev_defines, compile_variant):
+    """Instructions EXECUTED per time step of the bench kernel.  A stepper that moves its cache's reference point only every
+    K-th step (RMT_KC_REFRESH, csrc/kernels/50_rk4.inc) holds two versions of stage 1 in its step loop, one of which runs
+    per step: the static count of the loop is not what runs.  Two counting builds of the same source give the parts -
+    A: every step refreshes (K = 1), C: no step does (RMT_TIMING_KC_NEVER, results wrong, never launched) - and a step
+    executes A/K + C(1 - 1/K).  -> (mix dict, note)"""
+    from rmt_app_amd import isa
+    K = int(dev_defines.get("RMT_KC_REFRESH", 1))
+    if not (kname == "rmt_n2_rk4_reg" and str(dev_defines.get("RMT_KCACHE", "0")) == "1" and K > 1):
+        return loop, ""
+    A = isa.kernel_stats(compile_variant({"RMT_KC_REFRESH": "1"}), kname)["step_loop"]
+    Cn = isa.kernel_stats(compile_variant({"RMT_TIMING_KC_NEVER": "1"}), kname)["step_loop"]
+    mix = {k: A[k]/K + Cn[k]*(1.0 - 1.0/K) for k in ("valu", "valu_f64", "lane_moves")}
+    mix["scratch"] = loop["scratch"]            # (spills are a property of the build that runs)
+    note = ("; executed per step = (refresh step: %d of %d VALU)/%d + (other steps: %d of %d)*%d/%d, the loop holds both "
+            "versions of stage 1" % (A["valu_f64"], A["valu"], K, Cn["valu_f64"], Cn["valu"], K - 1, K))
+    return mix, note
+
+
 def prebuild(members=MEMBERS_PER_GPU, n_nodes=N_NODES):
     """Cross-compile (hipRTC; no GPU) every code object the default `python bench.py` run loads, into the in-tree
     cache that travels with the repository - called by __graft_entry__.build(), so the bench on a fresh GPU box
@@ -388,6 +407,9 @@ def prebuild(members=MEMBERS_PER_GPU, n_nodes=N_NODES):
                               compile_fn=lambda mdef: compile_mechanism(mech, n_nodes, defines=mdef, E=members))
     rows = ens.rows
     keys = ["main sweep kernel (%d bytes)" % len(ens.code)]
+    for extra in ({"RMT_KC_REFRESH": "1"}, {"RMT_TIMING_KC_NEVER": "1"}):      # executed_step_mix's counting builds
+        keys.append("counting build (%d bytes)" % len(compile_mechanism(
+            mech, n_nodes, defines={**ens.member_defines, **extra}, E=members)))
     # accuracy_vs_scipy_reference: rmtExe on the reference's test input, zNo = 20
     mi = INP.dme_script_input()
     m20 = plan.Mechanism(mi)
@@ -544,7 +566,11 @@ def main():
         kname = "rmt_n2_rk4_%s" % ("mem" if args.mode == "mem" else
                                    ("reg" if n_nodes <= dev.block*dev.npt else "chain"))
         ist = isa.kernel_stats(code_blob, kname)
-        loop = ist.get("step_loop") or ist["whole"]
+        loop, mix_note = executed_step_mix(
+            ist.get("step_loop") or ist["whole"], kname, dev.defines,
+            lambda extra: compile_mechanism(mech, n_nodes, block=args.block, npt=args.npt, lds_state=args.lds,
+                                            defines={**defines, **ens.member_defines, **extra}, E=E,
+                                            extra_opts=args.copt))
         f64_ops = loop["valu_f64"]/float(dev.npt)
         traffic, traffic_src = tracked_traffic(ist["kernel_digest"], E, n_nodes)
         valu_rate = E*n_nodes*RK4_PER_STEP*f64_ops/(kernel_ms/1e3)
@@ -579,8 +605,9 @@ def main():
             # the real ceiling of this kernel: fp64 vector issue; ops/node-step = v_*_f64 instructions in
             # the step loop of the launched code object / nodes per lane (rmt_app_amd/isa.py)
             "valu_fp64": {"ops_per_node_step": f64_ops, "ops_source": "llvm-objdump of code object %s, step loop "
-                          "of %s: %d v_*_f64 of %d VALU, %d scratch, %d lane moves" % (
-                              ist["digest"], kname, loop["valu_f64"], loop["valu"], loop["scratch"], loop["lane_moves"]),
+                          "of %s: %d v_*_f64 of %d VALU, %d scratch, %d lane moves%s" % (
+                              ist["digest"], kname, loop["valu_f64"], loop["valu"], loop["scratch"], loop["lane_moves"],
+                              mix_note),
                           "achieved_Tops": valu_rate/1e12, "peak_Tops": FP64_PEAK_TOPS,
                           "frac": valu_rate/(FP64_PEAK_TOPS*1e12),
                           # what this instruction mix could reach with no stall at all, from the measured issue costs

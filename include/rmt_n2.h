@@ -167,6 +167,12 @@ int rmt_n2_set_mode(rmt_n2_handle* h, int mode);
 /* how the last rk4 / rk45 / ros4 launch was laid out: workgroups (chunks) per reactor - 1 = one workgroup per reactor -
  * and the number of teams that worked through the ensemble (= E when every reactor had its own workgroup) */
 int rmt_n2_last_geometry(rmt_n2_handle* h, int* chunks, int* teams);
+/* Code objects whose on-chip RK4 steppers cache the temperature-only rate constants between the stages of a step
+ * (kernels/50_rk4.inc) integrate a reactor whose temperature moved out of the cache's range during a launch again with
+ * the plain stepper, inside the same rmt_n2_rk4 call (results are those of the plain stepper; the cost is that launch
+ * twice).  How many reactor-launches that has happened to since rmt_n2_create (0 for every other code object);
+ * synchronises the handle's stream. */
+int rmt_n2_fallbacks(rmt_n2_handle* h, uint64_t* count);
 /* timing of the last rk4/rk45/rhs launch in ms (HIP events on the handle's stream; synchronises) */
 int rmt_n2_last_kernel_ms(rmt_n2_handle* h, float* ms);
 

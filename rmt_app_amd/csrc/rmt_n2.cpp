@@ -233,8 +233,10 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     const size_t mbytes = (size_t)h->E * (RMT_N2_MEMBER_FIXED + h->S + h->NU) * sizeof(double);
     CREATE_OK(hipMalloc((void**)&h->d_members, mbytes));
     CREATE_OK(hipMemcpy(h->d_members, p->members, mbytes, hipMemcpyHostToDevice));
-    CREATE_OK(hipMalloc((void**)&h->d_flags, (size_t)h->E * sizeof(unsigned)));
-    CREATE_OK(hipMemset(h->d_flags, 0, (size_t)h->E * sizeof(unsigned)));
+    // one status word per reactor + one word behind them: how many reactor-launches the cached RK4 steppers handed to
+    // their plain twins so far (rmt_n2_fallbacks)
+    CREATE_OK(hipMalloc((void**)&h->d_flags, ((size_t)h->E + 1) * sizeof(unsigned)));
+    CREATE_OK(hipMemset(h->d_flags, 0, ((size_t)h->E + 1) * sizeof(unsigned)));
     CREATE_OK(hipEventCreate(&h->ev0));
     CREATE_OK(hipEventCreate(&h->ev1));
 #undef CREATE_OK
@@ -592,6 +594,16 @@ extern "C" int rmt_n1_profile(rmt_n2_handle* h, const double* members1, void* ou
     HIP_OK(hipModuleLaunchKernel(h->f_n1, (unsigned)((E + 63) / 64), 1, 1, 64, 1, 1, 0, h->stream, args, nullptr));
     HIP_OK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    return 0;
+}
+
+extern "C" int rmt_n2_fallbacks(rmt_n2_handle* h, uint64_t* count) {
+    if (!h || !count) return fail("null argument");
+    ON_DEVICE(h);
+    unsigned c = 0;
+    HIP_OK(hipMemcpyAsync(&c, h->d_flags + h->E, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    *count = c;
     return 0;
 }
 

@@ -67,6 +67,7 @@ def lib():
     L.rmt_n2_status.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.rmt_n2_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rmt_n2_last_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.rmt_n2_fallbacks.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rmt_n2_hiprtc_path.restype = cp
     L.rmt_n2_compile_options.restype = cp
     if L.rmt_n2_abi_version() != ABI_VERSION:

@@ -110,6 +110,9 @@ def rk45_geometry(V, N, fp32=False, chain=True, E=None):
     return block, npt, {"RMT_RK45_LDS": str(slots)}
 
 
+KC_REFRESH = 8          # csrc/kernels/50_rk4.inc RMT_KC_REFRESH: the cache's reference point moves every 8th step
+
+
 def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     """(defines, lds_state) with the on-chip RK4 stepper's cache of the temperature-only rate constants switched on where
     it has been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body; profiles/round3_kcache.md): the 512 x 2 geometry
@@ -128,6 +131,7 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     if not fits(fp32, block, npt, 1, gen=False):
         return defs, lds_state
     defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
+    defs.setdefault("RMT_KC_REFRESH", str(KC_REFRESH))
     return defs, 1
 
 
@@ -343,6 +347,13 @@ class N2Device:
         c, t = C.c_int(), C.c_int()
         hipbind.check(hipbind.lib().rmt_n2_last_geometry(self.h, C.byref(c), C.byref(t)))
         return c.value, t.value
+
+    def fallbacks(self):
+        """Reactor-launches the cached RK4 steppers handed to their plain twins so far (rmt_n2_fallbacks): a reactor whose
+        temperature left the range of its cached rate constants during a launch is integrated again in full."""
+        n = C.c_uint64()
+        hipbind.check(hipbind.lib().rmt_n2_fallbacks(self.h, C.byref(n)))
+        return int(n.value)
 
     def last_kernel_ms(self):
         ms = C.c_float()

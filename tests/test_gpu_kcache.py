@@ -34,6 +34,7 @@ def _run(mech, rows, IV, steps, dt=2e-6, **kw):
     dev.rk4(y, dt, steps)
     out, flags = y.cpu().numpy(), dev.status().copy()
     info = (dict(dev.defines), dev.lds_state)
+    _run.fallbacks = dev.fallbacks()
     dev.close()
     return out, flags, info
 
@@ -42,7 +43,8 @@ def test_cached_stepper_is_the_default_at_512x2_and_matches_plain_and_oracle():
     mech, rows, IV, inputs = _sweep(6)
     got, flags, (defs, lds) = _run(mech, rows, IV, 300)
     assert defs.get("RMT_KCACHE") == "1" and defs.get("RMT_KCACHE_GEN") == "0" and lds == 1
-    assert not flags.any()
+    assert int(defs.get("RMT_KC_REFRESH")) == 8            # the reference point moves every 8th step
+    assert not flags.any() and _run.fallbacks == 0
     plain, pflags, (pdefs, plds) = _run(mech, rows, IV, 300, defines={"RMT_KCACHE": "0"})
     assert pdefs["RMT_KCACHE"] == "0" and plds == 0 and not pflags.any()
     scale = np.max(np.abs(plain.reshape(6, 7, N)), axis=2, keepdims=True)
@@ -66,6 +68,7 @@ def test_reactors_that_leave_the_cache_range_are_integrated_again_in_full(thr):
                                                                    "RMT_KCACHE_THR": thr}, lds_state=1)
     assert defs["RMT_KCACHE_THR"] == thr and lds == 1
     assert not flags.any(), flags
+    assert _run.fallbacks == 8 if thr == "1e-12" else 0 < _run.fallbacks <= 8            # rmt_n2_fallbacks
     plain, pflags, _ = _run(mech, rows, IV, 150, defines={"RMT_KCACHE": "0"}, lds_state=1)
     assert not pflags.any()
     if thr == "1e-12":
@@ -125,6 +128,7 @@ def _run_chain(mech, rows, IV, steps, **kw):
     y = dev.to_device(IV)
     dev.rk4(y, 2e-6, steps)
     out, flags, info = y.cpu().numpy(), dev.status().copy(), (dict(dev.defines), dev.lds_state, dev.last_geometry())
+    _run_chain.fallbacks = dev.fallbacks()
     dev.close()
     return out, flags, info
 
@@ -155,6 +159,7 @@ def test_chained_reactors_that_leave_the_cache_range_are_integrated_again(thr):
     got, flags, (_, _, geo) = _run_chain(mech, rows, IV, 40, **kw)
     assert geo[0] == 3 and geo[1] < E
     assert not flags.any(), flags[flags != 0][:4]
+    assert _run_chain.fallbacks == E if thr == "1e-12" else 0 < _run_chain.fallbacks <= E
     plain, pflags, _ = _run_chain(mech, rows, IV, 40, defines={"RMT_KCACHE_CHAIN": "0"}, lds_state=1)
     assert not pflags.any()
     if thr == "1e-12":

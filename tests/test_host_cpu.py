@@ -697,13 +697,13 @@ def test_kcache_choice_and_the_code_object_it_builds():
     from rmt_app_amd import hipbind, isa
     from rmt_app_amd.n2 import device_source, kcache_choice
     dme = plan.Mechanism(INP.dme_notebook_input())
-    on = ({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0"}, 1)
+    on = ({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0", "RMT_KC_REFRESH": "8"}, 1)
     assert kcache_choice(dme, 1024, False, 512, 2, None, None) == on
     assert kcache_choice(dme, 1000, False, 512, 2, 1, {"X": "1"}) == (dict(on[0], X="1"), 1)
     assert kcache_choice(dme, 1024, False, 512, 2, 0, None) == ({}, 0)                  # the caller's lds_state wins
     assert kcache_choice(dme, 1024, False, 512, 2, None, {"RMT_KCACHE": "0"}) == ({"RMT_KCACHE": "0"}, None)
     assert kcache_choice(dme, 1024, True, 512, 2, None, None) == ({}, None)             # fp32
-    chain = ({"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0"}, 1)
+    chain = ({"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0", "RMT_KC_REFRESH": "8"}, 1)
     assert kcache_choice(dme, 4096, False, 512, 2, None, None) == chain                 # chained reactor: the chunks' cache
     assert kcache_choice(dme, 4096, False, 512, 2, None, {"RMT_KCACHE_CHAIN": "0"}) == ({"RMT_KCACHE_CHAIN": "0"}, None)
     assert kcache_choice(dme, 4096, False, 128, 1, None, None) == ({}, None)
@@ -715,7 +715,11 @@ def test_kcache_choice_and_the_code_object_it_builds():
     assert (block, npt) == (512, 2) and defs["RMT_KCACHE"] == "1" and "#define RMT_LDS_STATE 1" in src
     blob = hipbind.compile_cached(src, key, "gfx950")
     st = isa.kernel_stats(blob, "rmt_n2_rk4_reg")
-    assert st["step_loop"]["scratch"] == 0 and st["step_loop"]["valu"] < 3400           # (the plain stepper: 3689)
+    assert st["step_loop"]["scratch"] == 0 and st["step_loop"]["valu"] < 4100           # (both versions of stage 1)
+    from bench import executed_step_mix
+    mix, note = executed_step_mix(st["step_loop"], "rmt_n2_rk4_reg", defs, lambda extra: hipbind.compile_cached(
+        *device_source(dme, np.tile(row, (256, 1)), 1024, defines=extra)[3:5], "gfx950"))
+    assert mix["valu"] < 3150 and mix["scratch"] == 0 and "refresh step" in note         # (the plain stepper: 3689)
     assert isa.kernel_stats(blob, "rmt_n2_rk4_reg_redo")["whole"]["valu"] > 3000        # the plain stepper, same object
     _, row4 = plan.member_constants(INP.dme_notebook_input(), dme, 4096)
     block, npt, defs, src, key = device_source(dme, np.tile(row4, (256, 1)), 4096)

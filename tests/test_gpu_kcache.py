@@ -68,7 +68,8 @@ def test_reactors_that_leave_the_cache_range_are_integrated_again_in_full(thr):
                                                                    "RMT_KCACHE_THR": thr}, lds_state=1)
     assert defs["RMT_KCACHE_THR"] == thr and lds == 1
     assert not flags.any(), flags
-    assert _run.fallbacks == 8 if thr == "1e-12" else 0 < _run.fallbacks <= 8            # rmt_n2_fallbacks
+    lo, hi = {"1e-12": (8, 8), "3e-7": (1, 8), "2e-5": (0, 8)}[thr]                      # rmt_n2_fallbacks
+    assert lo <= _run.fallbacks <= hi, _run.fallbacks
     plain, pflags, _ = _run(mech, rows, IV, 150, defines={"RMT_KCACHE": "0"}, lds_state=1)
     assert not pflags.any()
     if thr == "1e-12":

@@ -21,6 +21,7 @@ math/numpy elementwise functions, ...) raise ``LoweringError`` - there is no CPU
 """
 import hashlib
 import math
+import os
 import types
 
 import numpy as np
@@ -889,7 +890,15 @@ class Lowered:
         ``slot`` / ``fslot`` (cache slot of the value / of a "gen" exponent), ``slots`` (doubles per mesh node),
         ``branch`` (nodes evaluated inside the cached section, roots included), ``prologue`` (their root-free
         T-only ancestors, evaluated before it).  ``gen=False`` leaves the "gen" constants (two slots each) out of the
-        cache: they are evaluated in full on either path (their log(T) still comes from the cache)."""
+        cache: they are evaluated in full on either path (their log(T) still comes from the cache).
+
+        ``gen="basis"``: an exponent that is a LINEAR COMBINATION of T^n (|n| <= 4) and log T - the usual form of an
+        equilibrium constant, ln K = a/T + b ln T + c T + d T^2 + ... - needs no stored exponent: f(T) - f(T_ref) is the
+        same combination of the differences of the basis functions, which follow from T - T_ref, 1/T - 1/T_ref and
+        log1p(T/T_ref - 1) in a handful of operations shared by all such constants.  kind = ("basis", {key: coef}) with
+        keys ("p", n) / ("log",), one slot each; ``tslot`` = slot of T_ref (when a positive power occurs).  Exponents that
+        do not decompose stay out of the cache.  ``outside_exp``: True when some exp-family node of the DAG is NOT a
+        root (its evaluation needs the exp table whatever the path)."""
         g = self.g
         live = sorted(self.live)
 
@@ -919,12 +928,83 @@ class Lowered:
             if op == "div" and g.is_const(a) and g.nodes[b] == ("in", "T", None):
                 return g.cval(a)
             return None
+        def basis(i, memo={}):
+            """{key: coef} if node i is a linear combination of T^n and log T (constant term under ("c",)), else None."""
+            if i in memo:
+                return memo[i]
+            op, a, b = g.nodes[i]
+            out = None
+            mono = lambda d: d is not None and len(d) == 1 and next(iter(d))[0] in ("p", "c")
+            def scaled(d, c):
+                return None if d is None else {k: v*c for k, v in d.items()}
+            def times(x, y):                      # monomial x monomial
+                (kx, cx), (ky, cy) = next(iter(x.items())), next(iter(y.items()))
+                n = (kx[1] if kx[0] == "p" else 0) + (ky[1] if ky[0] == "p" else 0)
+                return {(("p", n) if n else ("c",)): cx*cy}
+            if op == "const":
+                out = {("c",): g.cval(i)}
+            elif op == "in":
+                out = {("p", 1): 1.0} if a == "T" else None
+            elif op == "log":
+                out = {("log",): 1.0} if g.nodes[a] == ("in", "T", None) else None
+            elif op == "neg":
+                out = scaled(basis(a), -1.0)
+            elif op in ("add", "sub"):
+                x, y = basis(a), basis(b)
+                if x is not None and y is not None:
+                    out = dict(x)
+                    for k, v in y.items():
+                        out[k] = out.get(k, 0.0) + (v if op == "add" else -v)
+            elif op == "mul":
+                x, y = basis(a), basis(b)
+                if x is not None and y is not None:
+                    if set(x) == {("c",)}:
+                        out = scaled(y, x[("c",)])
+                    elif set(y) == {("c",)}:
+                        out = scaled(x, y[("c",)])
+                    elif mono(x) and mono(y):
+                        out = times(x, y)
+                    elif mono(x) and all(k[0] in ("p", "c") for k in y):
+                        out = {}
+                        for k, v in y.items():
+                            out.update(times(x, {k: v}))
+                    elif mono(y) and all(k[0] in ("p", "c") for k in x):
+                        out = {}
+                        for k, v in x.items():
+                            out.update(times(y, {k: v}))
+            elif op in ("rcp", "div"):
+                den = basis(a if op == "rcp" else b)
+                num = {("c",): 1.0} if op == "rcp" else basis(a)
+                if mono(den) and num is not None and next(iter(den.values())) != 0.0 \
+                        and all(k[0] in ("p", "c") for k in num):
+                    (kd, cd), = den.items()
+                    inv = {(("p", -kd[1]) if kd[0] == "p" else ("c",)): 1.0/cd}
+                    out = {}
+                    for k, v in num.items():
+                        out.update(times(inv, {k: v}))
+            elif op == "powi":
+                x = basis(a)
+                if mono(x):
+                    (kx, cx), = x.items()
+                    n = (kx[1] if kx[0] == "p" else 0)*b
+                    out = {(("p", n) if n else ("c",)): cx**b}
+            if out is not None and not all(math.isfinite(v) for v in out.values()):
+                out = None
+            memo[i] = out
+            return out
         roots = []
+        bases = {}
         for i in live:
             op, a, b = g.nodes[i]
             if op in self._EXP_ROOTS and tonly[a] and not g.is_const(a):
-                if gen or lin_in_invT(a) not in (None, 0.0):
+                if gen is True or lin_in_invT(a) not in (None, 0.0):
                     roots.append(i)
+                elif gen == "basis":
+                    d = basis(a, {})
+                    d = None if d is None else {k: v for k, v in d.items() if k != ("c",) and v != 0.0}
+                    if d and all(k == ("log",) or 1 <= abs(k[1]) <= 4 for k in d):
+                        bases[i] = d
+                        roots.append(i)
             elif op == "log" and g.nodes[a] == ("in", "T", None):
                 roots.append(i)
         if not roots:
@@ -952,14 +1032,21 @@ class Lowered:
             c = lin_in_invT(a)
             if c is not None and math.isfinite(c) and c != 0.0:
                 kind[r] = ("lin", c)
+            elif r in bases:
+                kind[r] = ("basis", bases[r])
             else:
                 kind[r] = "gen"
                 fslot[r] = nslots
                 nslots += 1
+        tslot = None
+        if any(k[0] == "p" and k[1] > 0 for d in bases.values() for k in d):
+            tslot = nslots
+            nslots += 1
         branch = [i for i in live if i in rootset or (i in need and dep[i] and not g.is_const(i))]
         prologue = [i for i in live if i in need and not dep[i] and i not in rootset]
+        outside = any(g.nodes[i][0] in self._EXP_ROOTS and i not in rootset for i in live)
         return {"roots": roots, "kind": kind, "slot": slot, "fslot": fslot, "slots": nslots, "branch": branch,
-                "prologue": prologue}
+                "prologue": prologue, "tslot": tslot, "outside_exp": outside}
 
     def emit(self, fname="rmt_kinetics", const_table=False, kcache=False, kcache_gen=True, kcache_thr=None):
         """The device function of the rates.  ``kcache``: with the cached section of kcache_plan() for callers that
@@ -1000,7 +1087,8 @@ class Lowered:
         and tests the range that step serves - |d| <= KC_THR in every exponent, |T/T_ref - 1| <= KC_THR for log(T) - a
         lane out of range only marks its cache (`kc.leave`: there is no second code path, the CALLER discards what it
         computed from such an evaluation, see csrc/kernels/50_rk4.inc rmt_rk4_reg_body); MODE 0 evaluates in full and
-        (with a cache) stores the new reference point."""
+        (with a cache) stores the new reference point.  Full evaluations made on behalf of a cache go through
+        rmt_exp_sel<KC::enabled> (00_config_math.inc): a caching kernel may keep a smaller exp table than the rest."""
         g = self.g
         emit = self._emitter()
         lines, name = [], {}
@@ -1017,40 +1105,78 @@ class Lowered:
         thr = repr(self._kc_thr)
         taylor = ("k_ + (k_ * d_) * (real(1) + d_ * (real(0.5) + d_ * (real(%r) + d_ * real(%r))))"
                   % (1.0/6.0, 1.0/24.0))
+        kinds = plan["kind"]
+        lin = [abs(self._EXP_ROOTS[g.nodes[r][0]][0]*self._EXP_ROOTS[g.nodes[r][0]][1]*kinds[r][1])
+               for r in plan["roots"] if isinstance(kinds[r], tuple) and kinds[r][0] == "lin"]
+        bases = {r: kinds[r][1] for r in plan["roots"] if isinstance(kinds[r], tuple) and kinds[r][0] == "basis"}
+        powers = sorted({k[1] for d in bases.values() for k in d if k[0] == "p"})
+        want_log = any(k == "log" for k in kinds.values()) or any(("log",) in d for d in bases.values())
         L = lines.append
         L("    if constexpr (KC::enabled && MODE == 2) {      // every constant from its cached value: K = K_ref e^d, d = f(T) - f(T_ref)")
         L("        const real kc_it = kc.get(0);")
         L("        const real kc_di = invT - kc_it;")
         L("        (void)kc_di;")
-        # the range test sits next to the values it shares with the Taylor steps
-        g_ = self.g
-        lin = [abs(self._EXP_ROOTS[g_.nodes[r][0]][0]*self._EXP_ROOTS[g_.nodes[r][0]][1]*plan["kind"][r][1])
-               for r in plan["roots"] if isinstance(plan["kind"][r], tuple)]
-        tests = []
+        tests = []                                        # the range test sits next to the values it shares with the Taylor steps
         if lin:
             tests.append("!(rmt_abs(kc_di) <= real(%r))" % (self._kc_thr/max(lin)))
-        if any(k == "log" for k in plan["kind"].values()):
-            tests.append("!(rmt_abs(T * kc_it - real(1)) <= real(%r))" % self._kc_thr)
+        if want_log:
+            L("        const real kc_s = T * kc_it - real(1);")
+            L("        const real kc_dl = kc_s * (real(1) + kc_s * (real(-0.5) + kc_s * (real(%r) + kc_s * (real(-0.25) + kc_s * real(0.2)))));      // log(T) - log(T_ref) = log1p(T/T_ref - 1)"
+              % (1.0/3.0))
+            tests.append("!(rmt_abs(kc_s) <= real(%r))" % self._kc_thr)
         if tests:
             L("        kc.leave(%s);" % " || ".join(tests))
+        # differences of the basis functions of the ("basis", ...) exponents: T^n - T_ref^n from (T - T_ref) or (1/T - 1/T_ref)
+        dname = {("log",): "kc_dl"}
+        if any(n > 0 for n in powers):
+            L("        const real kc_tr = kc.get(%d);" % plan["tslot"])
+            L("        const real kc_dt = T - kc_tr;")
+        for n in powers:
+            x, xr, dx = ("T", "kc_tr", "kc_dt") if n > 0 else ("invT", "kc_it", "kc_di")
+            m = abs(n)
+            nm = "kc_d%s%d" % ("p" if n > 0 else "m", m)
+            dname[("p", n)] = nm
+            if m == 1:
+                L("        const real %s = %s;" % (nm, dx))
+            elif m == 2:
+                L("        const real %s = %s * (%s + %s);" % (nm, dx, x, xr))
+            elif m == 3:
+                L("        const real %s = %s * (%s * (%s + %s) + %s * %s);" % (nm, dx, x, x, xr, xr, xr))
+            else:
+                L("        const real %s = (%s * (%s + %s)) * (%s * %s + %s * %s);" % (nm, dx, x, xr, x, x, xr, xr))
+        # ... consumed at once: only the exponents' changes stay live (one value per constant), with ONE range test for all
+        # of them (a NaN exponent implies a NaN temperature, which the tests above catch)
+        dmax = []
+        for i, d in bases.items():
+            sg, lnb = self._EXP_ROOTS[g.nodes[i][0]]
+            terms = " + ".join("real(%r) * %s" % (sg*lnb*c, dname[key]) for key, c in d.items())
+            L("        const real kc_e%d = %s;" % (i, terms))
+            dmax.append("rmt_abs(kc_e%d)" % i)
+        if dmax:
+            big = dmax[0]
+            for t in dmax[1:]:
+                big = "rmt_max(%s, %s)" % (big, t)
+            L("        kc.leave(!(%s <= real(%s)));" % (big, thr))
         for i in plan["branch"]:
             op, a, b = g.nodes[i]
             v = "v%d" % i
-            if i not in plan["kind"]:
+            if i not in kinds:
                 for ln in emit(i, name, declare=False, nocheck=True):
                     L("    " + ln)
                 continue
-            k = plan["kind"][i]
+            k = kinds[i]
             if k == "log":
-                L("        {   // log(T) = log(T_ref) + log1p(T/T_ref - 1)")
-                L("            const real s_ = T * kc_it - real(1);")
-                L("            %s = kc.get(%d) + s_ * (real(1) + s_ * (real(-0.5) + s_ * (real(%r) + s_ * (real(-0.25) + s_ * real(0.2)))));"
-                  % (v, plan["slot"][i], 1.0/3.0))
-                L("        }")
-            elif isinstance(k, tuple):
+                L("        %s = kc.get(%d) + kc_dl;" % (v, plan["slot"][i]))
+            elif k[0] == "lin":
                 sg, lnb = self._EXP_ROOTS[op]
                 L("        {")
                 L("            const real d_ = real(%r) * kc_di;" % (sg*lnb*k[1]))
+                L("            const real k_ = kc.get(%d);" % plan["slot"][i])
+                L("            %s = %s;" % (v, taylor))
+                L("        }")
+            elif k[0] == "basis":
+                L("        {")
+                L("            const real d_ = kc_e%d;" % i)
                 L("            const real k_ = kc.get(%d);" % plan["slot"][i])
                 L("            %s = %s;" % (v, taylor))
                 L("        }")
@@ -1065,8 +1191,13 @@ class Lowered:
             name[i] = v
         L("    } else {                 // full evaluation; with a cache its reference point moves here (every constant is")
         L("        if constexpr (KC::enabled) kc.put(0, invT);      // stored as soon as it exists: short live ranges)")
+        if plan.get("tslot") is not None:
+            L("        if constexpr (KC::enabled) kc.put(%d, T);" % plan["tslot"])
         for i in plan["branch"]:
             for ln in emit(i, name, declare=False):
+                if i in kinds and kinds[i] != "log":          # the table-driven exp of whoever owns the table
+                    for fn in ("rmt_exp10(", "rmt_exp2(", "rmt_exp("):
+                        ln = ln.replace(fn, fn[:-1] + "_sel<KC::enabled>(")
                 L("    " + ln)
             done.add(i)
             if i in plan["slot"]:

@@ -128,9 +128,18 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
             or lds_state not in (None, 1) or mech.V > 8):
         return defs, lds_state
     fits = mech.kcache_fits_chain if chained else mech.kcache_fits
-    if not fits(fp32, block, npt, 1, gen=False):
+    # the one-workgroup stepper also caches the equilibrium constants (policy "2": one slot each, the exponent's change from
+    # the differences of its basis functions) when that fits - it does with the 64-entry exp table, which a caching kernel
+    # can keep when every table-driven exp of the mechanism is a cached constant; otherwise they are evaluated in full
+    if not chained and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
+            and fits(fp32, block, npt, 1, gen="basis", small_exp=True, node_major=True):
+        # (a node's slots side by side in LDS: one address register per node; with slot-major rows of 8 KiB the far slots
+        # need registers of their own and the step loop spills - 1.86e10 against 1.97e10 node-steps/s)
+        defs.update({key: "1", "RMT_KCACHE_GEN": "2", "RMT_KC_SMALL_EXP": "1", "RMT_KC_NODE_MAJOR": "1"})
+    elif fits(fp32, block, npt, 1, gen=False):
+        defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
+    else:
         return defs, lds_state
-    defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
     defs.setdefault("RMT_KC_REFRESH", str(KC_REFRESH))
     return defs, 1
 
@@ -163,12 +172,16 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
         defs.update(plan.uniform_member_defines(members, mech.S))
     # "RMT_KCACHE": "1" (kcache_choice above, or the caller's own): the on-chip RK4 stepper caches the temperature-only
     # rate constants per node in LDS - that has to fit
-    gen = str(defs.get("RMT_KCACHE_GEN", "1")) == "1"
+    gen = plan.KCACHE_GEN[str(defs.get("RMT_KCACHE_GEN", "1"))]
+    small = str(defs.get("RMT_KC_SMALL_EXP", "0")) == "1"
+    if small and not mech.kcache_small_exp(gen):
+        raise ValueError("RMT_KC_SMALL_EXP=1: the mechanism has table-driven exp evaluations that are not cached constants")
     if str(defs.get("RMT_KCACHE_CHAIN", "0")) == "1" and not mech.kcache_fits_chain(fp32, block, npt, lds_state, gen):
         raise ValueError("RMT_KCACHE_CHAIN=1: the cache of the temperature-only rate constants (%d doubles per node) does "
                          "not fit beside the chunk's RK4 vectors (model N2, fp64)" % mech.kcache_slots(gen))
     if str(defs.get("RMT_KCACHE", "0")) == "1" and not (
-            int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state, gen)):
+            int(N) <= block*npt and mech.kcache_fits(fp32, block, npt, lds_state, gen, small,
+                                                     str(defs.get("RMT_KC_NODE_MAJOR", "0")) == "1")):
         raise ValueError("RMT_KCACHE=1: the cache of the temperature-only rate constants (%d doubles per node) does not "
                          "fit this geometry (needs the on-chip RK4 stepper with its vectors in registers, model N2, fp64)"
                          % mech.kcache_slots())

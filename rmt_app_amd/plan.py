@@ -90,6 +90,12 @@ def wilke(visc, x, MW):
     return tot
 
 
+# RMT_KCACHE_GEN: what a caching stepper does with constants whose exponent is not linear in 1/T (equilibrium constants):
+# "0" evaluates them in full, "1" caches value and exponent (two slots), "2" caches the value and forms the exponent's
+# change from the differences of its basis functions T^n, log T (one slot; lowering.Lowered.kcache_plan)
+KCACHE_GEN = {"0": False, "1": True, "2": "basis"}
+
+
 class Mechanism:
     """Ensemble-invariant part of a model: becomes literals in the generated kernel."""
 
@@ -248,27 +254,38 @@ class Mechanism:
         return fit
 
     def kcache_slots(self, gen=True):
-        """doubles per mesh node the cache of the temperature-only rate constants needs (0: nothing to cache)."""
+        """doubles per mesh node the cache of the temperature-only rate constants needs (0: nothing to cache).  `gen`:
+        the policy for constants whose exponent is not linear in 1/T, see lowering.Lowered.kcache_plan / KCACHE_GEN."""
         p = self.device_dag().kcache_plan(gen)
         return p["slots"] if p else 0
 
-    def kcache_fits(self, fp32, block, npt, lds_state=None, gen=True):
-        """True when the on-chip RK4 stepper can keep that cache in LDS: model N2 in fp64, its RK4 vectors in
-        registers (lds_state 0) and slots x nodes-per-workgroup doubles beside the exp table (16 KiB; 512 B for
-        one-wave workgroups) and the exchange buffers within 150 KiB."""
+    def _kcache_lds(self, fp32, block, npt, state_vectors, gen, small_exp, node_major=False):
+        """LDS bytes of a caching RK4 stepper: `state_vectors` of its long-lived vectors, the cache, the exp table (16 KiB;
+        512 B in the small form a caching kernel may keep, and for one-wave workgroups) and the exchange buffers."""
         slots = self.kcache_slots(gen)
         if not slots or fp32 or self.model != "N2":
-            return False
-        state = self.lds_state(fp32, block, npt, lds_state)*self.V*block*npt*8
-        return state + slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
+            return None
+        table = 512 if (small_exp or block <= 64) else 16384
+        nodes = block*npt
+        cache = nodes*((slots + 1) & ~1)*8 + nodes//4*8 if node_major else nodes*slots*8     # (RMT_KC_NODE_MAJOR: padded rows)
+        return state_vectors*self.V*nodes*8 + cache + table + 4096
 
-    def kcache_fits_chain(self, fp32, block, npt, lds_state=None, gen=True):
+    def kcache_small_exp(self, gen):
+        """True when a caching kernel can keep the 64-entry exp table: every table-driven exp of the mechanism is a cached
+        constant, i.e. full evaluations (two more multiply-adds each) only happen when the reference point moves."""
+        p = self.device_dag().kcache_plan(gen)
+        return bool(p) and not p["outside_exp"]
+
+    def kcache_fits(self, fp32, block, npt, lds_state=None, gen=True, small_exp=False, node_major=False):
+        """True when the on-chip RK4 stepper can keep that cache in LDS beside the vectors it keeps there (model N2,
+        fp64): within 158 KiB of the CU's 160."""
+        need = self._kcache_lds(fp32, block, npt, self.lds_state(fp32, block, npt, lds_state), gen, small_exp, node_major)
+        return need is not None and need <= 159*1024
+
+    def kcache_fits_chain(self, fp32, block, npt, lds_state=None, gen=True, small_exp=False):
         """The same cache in the chained RK4 stepper (RMT_KCACHE_CHAIN): beside the chunk's RK4 vectors in LDS."""
-        slots = self.kcache_slots(gen)
-        if not slots or fp32 or self.model != "N2":
-            return False
-        state = self.lds_state(fp32, block, npt, lds_state, chained=True)*self.V*block*npt*8
-        return state + slots*block*npt*8 + (16384 if block > 64 else 512) + 6144 <= 150*1024
+        need = self._kcache_lds(fp32, block, npt, self.lds_state(fp32, block, npt, lds_state, chained=True), gen, small_exp)
+        return need is not None and need <= 158*1024
 
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""
@@ -277,7 +294,7 @@ class Mechanism:
         kin = self.device_dag().emit("rmt_kinetics", const_table=bool((defines or {}).get("RMT_KINETICS_KTAB")),
                                      kcache=(str((defines or {}).get("RMT_KCACHE", "0")) == "1"
                                              or str((defines or {}).get("RMT_KCACHE_CHAIN", "0")) == "1"),
-                                     kcache_gen=str((defines or {}).get("RMT_KCACHE_GEN", "1")) == "1",
+                                     kcache_gen=KCACHE_GEN[str((defines or {}).get("RMT_KCACHE_GEN", "1"))],
                                      kcache_thr=(defines or {}).get("RMT_KCACHE_THR"))
         if (defines or {}).get("RMT_WITH_ROS4"):
             # the stiff stepper's node Jacobian is analytic: rates AND their partials by T, x_i, C_i

@@ -42,7 +42,8 @@ def _run(mech, rows, IV, steps, dt=2e-6, **kw):
 def test_cached_stepper_is_the_default_at_512x2_and_matches_plain_and_oracle():
     mech, rows, IV, inputs = _sweep(6)
     got, flags, (defs, lds) = _run(mech, rows, IV, 300)
-    assert defs.get("RMT_KCACHE") == "1" and defs.get("RMT_KCACHE_GEN") == "0" and lds == 1
+    assert defs.get("RMT_KCACHE") == "1" and defs.get("RMT_KCACHE_GEN") == "2" and lds == 1      # equilibrium constants too
+    assert defs.get("RMT_KC_SMALL_EXP") == "1" and defs.get("RMT_KC_NODE_MAJOR") == "1"
     assert int(defs.get("RMT_KC_REFRESH")) == 8            # the reference point moves every 8th step
     assert not flags.any() and _run.fallbacks == 0
     plain, pflags, (pdefs, plds) = _run(mech, rows, IV, 300, defines={"RMT_KCACHE": "0"})

@@ -690,6 +690,38 @@ def test_kcache_plan_and_emission_for_the_test_mechanisms(template):
                       defines={"RMT_KCACHE": "1"})
 
 
+def test_kcache_basis_decomposition_of_the_equilibrium_constants():
+    """kcache_plan("basis"): ln K of the three DME equilibrium constants as a linear combination of T^n and log T - the
+    ratio K(T2)/K(T1) of the DAG's own evaluation equals exp of the same combination of the basis functions' differences
+    (what the cached path computes, kernels' MODE 2), and the emitted source carries the difference formulas."""
+    import math
+    dme = plan.Mechanism(INP.dme_notebook_input())
+    dag = dme.device_dag()
+    p = dag.kcache_plan("basis")
+    based = [r for r in p["roots"] if isinstance(p["kind"][r], tuple) and p["kind"][r][0] == "basis"]
+    assert len(based) == 3 and p["slots"] == 12 and p["tslot"] == 11 and not p["outside_exp"]
+    sub = lowering.Lowered(dag.g, based, dag.S)
+    x = [0.5, 0.2, 0.05, 0.2, 0.03, 0.02]
+    T1, T2 = 521.3, 521.3 + 0.0612
+    K1, K2 = sub.evaluate(T1, 5e6, x, x), sub.evaluate(T2, 5e6, x, x)
+    for r, k1, k2 in zip(based, K1, K2):
+        sg, lnb = dag._EXP_ROOTS[dag.g.nodes[r][0]]
+        d = 0.0
+        for key, c in p["kind"][r][1].items():
+            d += c*((math.log(T2) - math.log(T1)) if key == ("log",) else (T2**key[1] - T1**key[1]))
+        assert abs(k2/k1 - math.exp(sg*lnb*d)) < 2e-13*abs(k2/k1)
+    src = dme.source(hipbind_template(), defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "2"})
+    assert "#define RMT_KC_SLOTS 12" in src and "kc_dp3" in src and "kc_dm3" in src and "rmt_exp_sel<KC::enabled>(" in src
+    # a mechanism without such constants: nothing changes; exponents that do not decompose stay out of the cache
+    syn = plan.Mechanism(INP.syn12_input())
+    assert syn.kcache_slots("basis") == syn.kcache_slots(False) == 9 and syn.kcache_small_exp("basis")
+
+
+def hipbind_template():
+    from rmt_app_amd import hipbind
+    return hipbind.kernel_template()
+
+
 def test_kcache_choice_and_the_code_object_it_builds():
     """n2.kcache_choice: the cache is switched on for the measured geometry only (512 x 2, model N2, fp64, a reactor that
     fits the workgroup), with y_n in LDS; an explicit RMT_KCACHE or another lds_state is left alone.  The code object then
@@ -697,7 +729,8 @@ def test_kcache_choice_and_the_code_object_it_builds():
     from rmt_app_amd import hipbind, isa
     from rmt_app_amd.n2 import device_source, kcache_choice
     dme = plan.Mechanism(INP.dme_notebook_input())
-    on = ({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0", "RMT_KC_REFRESH": "8"}, 1)
+    on = ({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "2", "RMT_KC_SMALL_EXP": "1", "RMT_KC_NODE_MAJOR": "1",
+           "RMT_KC_REFRESH": "8"}, 1)
     assert kcache_choice(dme, 1024, False, 512, 2, None, None) == on
     assert kcache_choice(dme, 1000, False, 512, 2, 1, {"X": "1"}) == (dict(on[0], X="1"), 1)
     assert kcache_choice(dme, 1024, False, 512, 2, 0, None) == ({}, 0)                  # the caller's lds_state wins

@@ -114,29 +114,41 @@ KC_REFRESH = 8          # csrc/kernels/50_rk4.inc RMT_KC_REFRESH: the cache's re
 
 
 def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
-    """(defines, lds_state) with the on-chip RK4 stepper's cache of the temperature-only rate constants switched on where
-    it has been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body; profiles/round3_kcache.md): the 512 x 2 geometry
-    of model N2 in fp64 - one workgroup per reactor (RMT_KCACHE; the bench shape, 1.62e10 -> 1.81e10 node-steps/s) or
-    chained workgroups (RMT_KCACHE_CHAIN; reactors beyond 1024 nodes in ensembles that fill the chip).  The cache holds
-    1/T_ref, log T_ref and the constants whose exponent is linear in 1/T (Arrhenius; RMT_KCACHE_GEN 0), y_n moves to LDS
-    (lds_state 1) to make room in the register file: with both the step loop has no spill.  An explicit "RMT_KCACHE" in
-    `defines` (0 or 1) or an lds_state other than 1 is left alone."""
+    """(defines, lds_state) with the RK4 steppers' cache of the temperature-only rate constants switched on where it has
+    been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body / rmt_rk4_chain_body; profiles/round3_kcache.md), model
+    N2 in fp64 with at most 8 variables per node:
+
+    * one workgroup per reactor at 512 x 2 (RMT_KCACHE; the bench shape, 1.62e10 -> 1.95e10 node-steps/s): 1/T_ref,
+      log T_ref, T_ref, the Arrhenius constants AND the equilibrium constants (RMT_KCACHE_GEN 2: one slot each, the
+      exponent's change from the differences of its basis functions T^n, log T) when the mechanism's exponents decompose
+      that way and every table-driven exp is then a cached constant (the kernel keeps the 64-entry exp table, which makes
+      the room in LDS); else without the equilibrium constants (RMT_KCACHE_GEN 0).  y_n moves to LDS (lds_state 1) to make
+      room in the register file; the reference point moves every 8th step;
+    * chained workgroups, every geometry (RMT_KCACHE_CHAIN, RMT_KCACHE_GEN 0): 256 x 4096 nodes at 512 x 2 +10 %, 128 x
+      1024 at 256 x 2 +8 %, 64 x 1024 at 256 x 1 +5 %, ONE 4096-node reactor at 128 x 1 +7.5 %.
+
+    An explicit "RMT_KCACHE" / "RMT_KCACHE_CHAIN" in `defines` (0 or 1) is left alone, and so is an lds_state that does
+    not leave the room."""
     defs = dict(defines or {})
     chained = int(N) > int(block)*int(npt)
     key = "RMT_KCACHE_CHAIN" if chained else "RMT_KCACHE"
-    if (key in defs or fp32 or getattr(mech, "model", "N2") != "N2" or (int(block), int(npt)) != (512, 2)
-            or lds_state not in (None, 1) or mech.V > 8):
+    wide = (int(block), int(npt)) == (512, 2)                 # two waves per SIMD at the register limit: y_n has to move
+    if key in defs or fp32 or getattr(mech, "model", "N2") != "N2" or mech.V > 8 or int(npt) > 2:
         return defs, lds_state
-    fits = mech.kcache_fits_chain if chained else mech.kcache_fits
-    # the one-workgroup stepper also caches the equilibrium constants (policy "2": one slot each, the exponent's change from
-    # the differences of its basis functions) when that fits - it does with the 64-entry exp table, which a caching kernel
-    # can keep when every table-driven exp of the mechanism is a cached constant; otherwise they are evaluated in full
-    if not chained and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
-            and fits(fp32, block, npt, 1, gen="basis", small_exp=True, node_major=True):
+    if chained:
+        want = 1 if wide else lds_state
+        if (wide and lds_state not in (None, 1)) or not mech.kcache_fits_chain(fp32, block, npt, want, gen=False):
+            return defs, lds_state
+        defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
+        return defs, want
+    if not wide or lds_state not in (None, 1):
+        return defs, lds_state
+    if mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
+            and mech.kcache_fits(fp32, block, npt, 1, gen="basis", small_exp=True, node_major=True):
         # (a node's slots side by side in LDS: one address register per node; with slot-major rows of 8 KiB the far slots
-        # need registers of their own and the step loop spills - 1.86e10 against 1.97e10 node-steps/s)
+        # need registers of their own and the step loop spills - 1.86e10 against 1.95e10 node-steps/s)
         defs.update({key: "1", "RMT_KCACHE_GEN": "2", "RMT_KC_SMALL_EXP": "1", "RMT_KC_NODE_MAJOR": "1"})
-    elif fits(fp32, block, npt, 1, gen=False):
+    elif mech.kcache_fits(fp32, block, npt, 1, gen=False):
         defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
     else:
         return defs, lds_state
@@ -176,7 +188,8 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
     small = str(defs.get("RMT_KC_SMALL_EXP", "0")) == "1"
     if small and not mech.kcache_small_exp(gen):
         raise ValueError("RMT_KC_SMALL_EXP=1: the mechanism has table-driven exp evaluations that are not cached constants")
-    if str(defs.get("RMT_KCACHE_CHAIN", "0")) == "1" and not mech.kcache_fits_chain(fp32, block, npt, lds_state, gen):
+    if str(defs.get("RMT_KCACHE_CHAIN", "0")) == "1" and not mech.kcache_fits_chain(
+            fp32, block, npt, lds_state, gen, small, str(defs.get("RMT_KC_NODE_MAJOR", "0")) == "1"):
         raise ValueError("RMT_KCACHE_CHAIN=1: the cache of the temperature-only rate constants (%d doubles per node) does "
                          "not fit beside the chunk's RK4 vectors (model N2, fp64)" % mech.kcache_slots(gen))
     if str(defs.get("RMT_KCACHE", "0")) == "1" and not (

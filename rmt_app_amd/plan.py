@@ -282,10 +282,11 @@ class Mechanism:
         need = self._kcache_lds(fp32, block, npt, self.lds_state(fp32, block, npt, lds_state), gen, small_exp, node_major)
         return need is not None and need <= 159*1024
 
-    def kcache_fits_chain(self, fp32, block, npt, lds_state=None, gen=True, small_exp=False):
+    def kcache_fits_chain(self, fp32, block, npt, lds_state=None, gen=True, small_exp=False, node_major=False):
         """The same cache in the chained RK4 stepper (RMT_KCACHE_CHAIN): beside the chunk's RK4 vectors in LDS."""
-        need = self._kcache_lds(fp32, block, npt, self.lds_state(fp32, block, npt, lds_state, chained=True), gen, small_exp)
-        return need is not None and need <= 158*1024
+        need = self._kcache_lds(fp32, block, npt, self.lds_state(fp32, block, npt, lds_state, chained=True), gen, small_exp,
+                                node_major)
+        return need is not None and need <= 159*1024
 
     def source(self, template, fp32=False, block=1024, npt=1, lds_state=None, defines=None):
         """Complete translation unit: prelude + template with the lowered kinetics spliced in."""

@@ -736,11 +736,13 @@ def test_kcache_choice_and_the_code_object_it_builds():
     assert kcache_choice(dme, 1024, False, 512, 2, 0, None) == ({}, 0)                  # the caller's lds_state wins
     assert kcache_choice(dme, 1024, False, 512, 2, None, {"RMT_KCACHE": "0"}) == ({"RMT_KCACHE": "0"}, None)
     assert kcache_choice(dme, 1024, True, 512, 2, None, None) == ({}, None)             # fp32
-    chain = ({"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0", "RMT_KC_REFRESH": "8"}, 1)
+    chain = ({"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0"}, 1)
     assert kcache_choice(dme, 4096, False, 512, 2, None, None) == chain                 # chained reactor: the chunks' cache
     assert kcache_choice(dme, 4096, False, 512, 2, None, {"RMT_KCACHE_CHAIN": "0"}) == ({"RMT_KCACHE_CHAIN": "0"}, None)
-    assert kcache_choice(dme, 4096, False, 128, 1, None, None) == ({}, None)
-    assert kcache_choice(dme, 1024, False, 256, 1, None, None) == ({}, None)            # other geometries: not measured
+    assert kcache_choice(dme, 4096, False, 128, 1, None, None) == (chain[0], None)      # the small chunks of ONE long reactor
+    assert kcache_choice(dme, 1024, False, 256, 1, None, None) == (chain[0], None)      # a small ensemble, chained
+    assert kcache_choice(dme, 1024, False, 1024, 1, None, None) == ({}, None)           # one workgroup, another geometry
+    assert kcache_choice(plan.Mechanism(INP.syn12_input()), 1024, False, 256, 2, None, None) == ({}, None)      # V = 13
     assert kcache_choice(plan.Mechanism(INP.ch4_input()), 1024, False, 512, 2, None, None) == ({}, None)   # nothing to cache
     assert kcache_choice(plan.Mechanism(INP.m2_dme_input()), 1024, False, 512, 2, None, None) == ({}, None)
     _, row = plan.member_constants(INP.dme_notebook_input(), dme, 1024)

@@ -381,7 +381,8 @@ def executed_step_mix(loop, kname, dev_defines, compile_variant):
     A: every step refreshes (K = 1), C: no step does (RMT_TIMING_KC_NEVER, results wrong, never launched) - and a step
     executes A/K + C(1 - 1/K).  -> (mix dict, note)"""
     from rmt_app_amd import isa
-    K = int(dev_defines.get("RMT_KC_REFRESH", 1))
+    from rmt_app_amd.n2 import kc_period
+    K = kc_period(dev_defines, DT)
     if not (kname == "rmt_n2_rk4_reg" and str(dev_defines.get("RMT_KCACHE", "0")) == "1" and K > 1):
         return loop, ""
     A = isa.kernel_stats(compile_variant({"RMT_KC_REFRESH": "1"}), kname)["step_loop"]

@@ -24,6 +24,8 @@ static thread_local std::string g_err;
 // workgroups per CU the single-evaluation kernel rmt_n2_rhs is launched with at most (it loops over the reactors): enough
 // to fill every wave slot the kernel's registers allow (4 per SIMD at 256 threads), with a second set queued behind
 #define RMT_N2_RHS_WGS_PER_CU 8
+// calls of rmt_n2_rk4 that run the plain on-chip stepper alone after a cached launch lost half of its reactors to it
+#define RMT_N2_PLAIN_LAUNCHES 8
 
 static int fail(const char* fmt, ...) {
     char buf[2048];
@@ -66,6 +68,14 @@ struct rmt_n2_handle {
     size_t work_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // cached one-workgroup RK4 stepper: the fallback counter is copied back behind every cached launch (pinned word +
+    // event, never waited for); when a launch lost at least half of its reactors to the plain stepper, the next
+    // RMT_N2_PLAIN_LAUNCHES calls run the plain stepper alone
+    unsigned* fb_host = nullptr;
+    hipEvent_t ev_fb = nullptr;
+    bool fb_pending = false;
+    unsigned fb_seen = 0;
+    int plain_left = 0;
     bool timed = false;
     int last_chunks = 1, last_teams = 0;     // geometry of the last stepper launch (rmt_n2_last_geometry)
 };
@@ -235,8 +245,12 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
     CREATE_OK(hipMemcpy(h->d_members, p->members, mbytes, hipMemcpyHostToDevice));
     // one status word per reactor + one word behind them: how many reactor-launches the cached RK4 steppers handed to
     // their plain twins so far (rmt_n2_fallbacks)
-    CREATE_OK(hipMalloc((void**)&h->d_flags, ((size_t)h->E + 1) * sizeof(unsigned)));
-    CREATE_OK(hipMemset(h->d_flags, 0, ((size_t)h->E + 1) * sizeof(unsigned)));
+    // (a second word behind them: non-zero = rmt_n2_rk4_reg_redo integrates EVERY reactor, the cached stepper is skipped)
+    CREATE_OK(hipMalloc((void**)&h->d_flags, ((size_t)h->E + 2) * sizeof(unsigned)));
+    CREATE_OK(hipMemset(h->d_flags, 0, ((size_t)h->E + 2) * sizeof(unsigned)));
+    CREATE_OK(hipHostMalloc((void**)&h->fb_host, 2 * sizeof(unsigned), hipHostMallocDefault));
+    h->fb_host[0] = h->fb_host[1] = 0u;
+    CREATE_OK(hipEventCreateWithFlags(&h->ev_fb, hipEventDisableTiming));
     CREATE_OK(hipEventCreate(&h->ev0));
     CREATE_OK(hipEventCreate(&h->ev1));
 #undef CREATE_OK
@@ -257,6 +271,8 @@ extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (h->d_sync) (void)hipFree(h->d_sync);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->d_rings) (void)hipFree(h->d_rings);
+    if (h->ev_fb) (void)hipEventDestroy(h->ev_fb);
+    if (h->fb_host) (void)hipHostFree(h->fb_host);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->module) (void)hipModuleUnload(h->module);
@@ -380,7 +396,31 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
                         h->block * h->npt, h->N);
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&dt, (void*)&ns,
                         (void*)&h->d_flags};
-        return launch(h, h->f_rk4_reg, args, -1, 1, 0, h->f_rk4_redo);
+        if (!h->f_rk4_redo) return launch(h, h->f_rk4_reg, args);
+        // a caching code object.  Did the last cached launch lose half of its reactors to the plain stepper (a transient
+        // faster than the cache's range serves)?  Then the cached stepper would only be run in vain for a while.
+        if (h->fb_pending && hipEventQuery(h->ev_fb) == hipSuccess) {
+            h->fb_pending = false;
+            const unsigned lost = h->fb_host[0] - h->fb_seen;
+            h->fb_seen = h->fb_host[0];
+            if (2u * lost >= (unsigned)h->E) {
+                h->plain_left = RMT_N2_PLAIN_LAUNCHES;
+                HIP_OK(hipMemsetAsync(h->d_flags + h->E + 1, 1, sizeof(unsigned), h->stream));
+            }
+        }
+        if (h->plain_left > 0) {
+            const int rc = launch(h, h->f_rk4_redo, args);
+            if (--h->plain_left == 0)
+                HIP_OK(hipMemsetAsync(h->d_flags + h->E + 1, 0, sizeof(unsigned), h->stream));
+            return rc;
+        }
+        if (launch(h, h->f_rk4_reg, args, -1, 1, 0, h->f_rk4_redo)) return 1;
+        if (!h->fb_pending) {
+            HIP_OK(hipMemcpyAsync(h->fb_host, h->d_flags + h->E, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipEventRecord(h->ev_fb, h->stream));
+            h->fb_pending = true;
+        }
+        return 0;
     }
     // chained workgroups: C chunks per reactor, T teams, every workgroup resident (T*C <= #CUs)
     const int W = h->block * h->npt;

@@ -110,7 +110,16 @@ def rk45_geometry(V, N, fp32=False, chain=True, E=None):
     return block, npt, {"RMT_RK45_LDS": str(slots)}
 
 
-KC_REFRESH = 8          # csrc/kernels/50_rk4.inc RMT_KC_REFRESH: the cache's reference point moves every 8th step
+KC_REFRESH = 8          # csrc/kernels/50_rk4.inc RMT_KC_REFRESH: the cache's reference point moves every 8th step ...
+KC_MAX_AGE = 1.7e-5     # ... RMT_KC_MAX_AGE: or sooner, so that no reference point is older than this much model time [s]
+
+
+def kc_period(defines, dt):
+    """steps between two moves of the reference point of a caching one-workgroup RK4 stepper at step size dt (the kernel's
+    own rule, csrc/kernels/50_rk4.inc rmt_rk4_reg_body)."""
+    K = int(defines.get("RMT_KC_REFRESH", 1))
+    age = float(defines.get("RMT_KC_MAX_AGE", KC_MAX_AGE))
+    return 1 if K <= 1 or not dt > 0 else int(min(float(K), max(1.0, age/dt)))
 
 
 def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
@@ -118,7 +127,9 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body / rmt_rk4_chain_body; profiles/round3_kcache.md), model
     N2 in fp64 with at most 8 variables per node:
 
-    * one workgroup per reactor at 512 x 2 (RMT_KCACHE; the bench shape, 1.62e10 -> 1.95e10 node-steps/s): 1/T_ref,
+    * one workgroup per reactor at 512 x 2 (RMT_KCACHE; the bench shape, 1.62e10 -> 1.95e10 node-steps/s) and at the
+      small geometries of short reactors (2048 x 20 nodes at 64 x 1: 3.2e9 -> 5.0e9, 2048 x 128 at 128 x 1: 1.21e10 ->
+      1.53e10, 1024 x 256 at 256 x 1: 1.47e10 -> 1.58e10; profiles/round3_kcache.md): 1/T_ref,
       log T_ref, T_ref, the Arrhenius constants AND the equilibrium constants (RMT_KCACHE_GEN 2: one slot each, the
       exponent's change from the differences of its basis functions T^n, log T) when the mechanism's exponents decompose
       that way and every table-driven exp is then a cached constant (the kernel keeps the 64-entry exp table, which makes
@@ -141,19 +152,24 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
             return defs, lds_state
         defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
         return defs, want
-    if not wide or lds_state not in (None, 1):
+    # one workgroup per reactor: 512 x 2 and the small geometries of short reactors (block <= 256, one node per lane);
+    # 512 x 1 measured SLOWER with the cache (1.54e10 -> 1.39-1.48e10) and stays plain
+    if not (wide or (int(npt) == 1 and int(block) <= 256)) or (wide and lds_state not in (None, 1)):
         return defs, lds_state
-    if mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
-            and mech.kcache_fits(fp32, block, npt, 1, gen="basis", small_exp=True, node_major=True):
+    want = 1 if wide else lds_state
+    # equilibrium constants too where that measured faster: everywhere but at 128 threads (1.53e10 with the Arrhenius
+    # constants alone against 1.39e10 - the wider kernel loses a wave of occupancy there)
+    if int(block) != 128 and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
+            and mech.kcache_fits(fp32, block, npt, want, gen="basis", small_exp=True, node_major=True):
         # (a node's slots side by side in LDS: one address register per node; with slot-major rows of 8 KiB the far slots
-        # need registers of their own and the step loop spills - 1.86e10 against 1.95e10 node-steps/s)
+        # need registers of their own and the 512 x 2 step loop spills - 1.86e10 against 1.95e10 node-steps/s)
         defs.update({key: "1", "RMT_KCACHE_GEN": "2", "RMT_KC_SMALL_EXP": "1", "RMT_KC_NODE_MAJOR": "1"})
-    elif mech.kcache_fits(fp32, block, npt, 1, gen=False):
+    elif mech.kcache_fits(fp32, block, npt, want, gen=False):
         defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
     else:
         return defs, lds_state
     defs.setdefault("RMT_KC_REFRESH", str(KC_REFRESH))
-    return defs, 1
+    return defs, want
 
 
 def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=None, defines=None,

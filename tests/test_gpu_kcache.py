@@ -182,3 +182,42 @@ def test_chained_cached_stepper_reports_python_exceptions_of_clean_and_redone_re
     _, flags, _ = _run_chain(mech, rows, IV, 2, defines={"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0",
                                                           "RMT_KCACHE_THR": "1e-12"}, lds_state=1)
     assert flags[1] & FLAG_DOMAIN and not flags[0] and not flags[2] and not flags[3]
+
+
+def test_a_launch_that_loses_its_reactors_switches_the_next_ones_to_the_plain_stepper():
+    """rmt_n2_rk4's host policy for caching code objects: the fallback counter comes back behind every cached launch; after
+    a launch that lost at least half of its reactors the next 8 calls run the plain stepper alone (no wasted cached pass),
+    then the cached one is tried again.  Shrunken range = every cached launch loses all of them; synchronising between the
+    calls makes the sequence deterministic: cached, 8 x plain, cached, 2 x plain."""
+    import torch
+    E = 6
+    mech, rows, IV, _ = _sweep(E)
+    dev = N2Device(mech, rows, N, block=512, npt=2, lds_state=1,
+                   defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0", "RMT_KCACHE_THR": "1e-12"})
+    y = dev.to_device(IV)
+    counts = []
+    for _ in range(12):
+        dev.rk4(y, 2e-6, 10)
+        torch.cuda.synchronize()
+        counts.append(dev.fallbacks())
+    assert counts == [E]*9 + [2*E]*3, counts
+    assert not dev.status().any()
+    got = y.cpu().numpy()
+    dev.close()
+    plain, pflags, _ = _run(mech, rows, IV, 120, defines={"RMT_KCACHE": "0"}, lds_state=1)
+    np.testing.assert_array_equal(got, plain)
+
+
+def test_refresh_period_follows_the_step_size():
+    """n2.kc_period = the kernel's rule: at most RMT_KC_REFRESH steps and no reference point older than 17 us of model
+    time; a large step (one refresh per step) and the default one give the plain stepper's result."""
+    from rmt_app_amd.n2 import kc_period
+    d = {"RMT_KC_REFRESH": "8"}
+    assert [kc_period(d, dt) for dt in (2e-6, 2.5e-6, 5e-6, 1e-5, 1e-4)] == [8, 6, 3, 1, 1] and kc_period({}, 2e-6) == 1
+    mech, rows, IV, _ = _sweep(3)
+    for dt, steps in ((1e-6, 200), (4e-6, 60)):
+        got, flags, _ = _run(mech, rows, IV, steps, dt=dt)
+        plain, pflags, _ = _run(mech, rows, IV, steps, dt=dt, defines={"RMT_KCACHE": "0"})
+        assert not flags.any() and not pflags.any() and _run.fallbacks == 0
+        scale = np.max(np.abs(plain.reshape(3, 7, N)), axis=2, keepdims=True)
+        assert np.max(np.abs(got - plain).reshape(3, 7, N)/scale) < 2e-13

@@ -993,18 +993,23 @@ class Lowered:
             memo[i] = out
             return out
         roots = []
-        bases = {}
+        bases, lins = {}, {}
         for i in live:
             op, a, b = g.nodes[i]
             if op in self._EXP_ROOTS and tonly[a] and not g.is_const(a):
-                if gen is True or lin_in_invT(a) not in (None, 0.0):
+                d = basis(a, {})                  # (an additive constant in the exponent drops out of every difference)
+                d = None if d is None else {k: v for k, v in d.items() if k != ("c",) and v != 0.0}
+                c = lin_in_invT(a)
+                if c in (None, 0.0) and d and set(d) == {("p", -1)}:
+                    c = d[("p", -1)]              # c/T + const: Arrhenius written relative to a reference temperature
+                if c not in (None, 0.0) and math.isfinite(c):
+                    lins[i] = c
                     roots.append(i)
-                elif gen == "basis":
-                    d = basis(a, {})
-                    d = None if d is None else {k: v for k, v in d.items() if k != ("c",) and v != 0.0}
-                    if d and all(k == ("log",) or 1 <= abs(k[1]) <= 4 for k in d):
-                        bases[i] = d
-                        roots.append(i)
+                elif gen is True:
+                    roots.append(i)
+                elif gen == "basis" and d and all(k == ("log",) or 1 <= abs(k[1]) <= 4 for k in d):
+                    bases[i] = d
+                    roots.append(i)
             elif op == "log" and g.nodes[a] == ("in", "T", None):
                 roots.append(i)
         if not roots:
@@ -1029,9 +1034,8 @@ class Lowered:
             if op == "log":
                 kind[r] = "log"
                 continue
-            c = lin_in_invT(a)
-            if c is not None and math.isfinite(c) and c != 0.0:
-                kind[r] = ("lin", c)
+            if r in lins:
+                kind[r] = ("lin", lins[r])
             elif r in bases:
                 kind[r] = ("basis", bases[r])
             else:

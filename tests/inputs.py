@@ -309,6 +309,21 @@ def syn12_kinetics(seed=20260410):
     return {"VARS": varis0, "RATES": rates0}
 
 
+def ch4_arrhenius_input(ivp="default", period=10, composition_exp=True):
+    """The CH4 case with a rate law that has what the caching steppers tell apart: an Arrhenius constant (exponent linear
+    in 1/T), an equilibrium-type constant whose exponent is a polynomial in T, 1/T and log T, an exponent that does NOT
+    decompose (exp of sqrt T) and - with composition_exp - an exp of the composition, which is not a function of the
+    temperature at all (it needs the big exp table whatever the path)."""
+    import math
+    mi = ch4_input(ivp, period)
+    damp = (lambda x: math.exp(-3.0*x['y_CH4'])) if composition_exp else (lambda x: 1.0)
+    mi["reaction-rates"]["RATES"] = {
+        "r1": lambda x: (x['k0']*math.exp(9000.0/973.0 - 9000.0/x['T'])*(x['C_CH4']**2)*damp(x)
+                         / (1.0 + 0.01*math.exp(2.0 - 1500.0/x['T'] + 0.3*math.log(x['T']) - 1e-3*x['T'] + 2e-7*x['T']**2))
+                         * (1.0 + 1e-3*math.exp(-math.sqrt(x['T'])/40.0)))}
+    return mi
+
+
 def syn12_input(ivp="default", period=0.5):
     P = 2.0e6
     T = 600

@@ -221,3 +221,43 @@ def test_refresh_period_follows_the_step_size():
         assert not flags.any() and not pflags.any() and _run.fallbacks == 0
         scale = np.max(np.abs(plain.reshape(3, 7, N)), axis=2, keepdims=True)
         assert np.max(np.abs(got - plain).reshape(3, 7, N)/scale) < 2e-13
+
+
+@pytest.mark.parametrize("composition_exp", [True, False])
+def test_mechanism_with_every_kind_of_exponent_cached_vs_plain_and_oracle(composition_exp):
+    """inputs.ch4_arrhenius_input: an Arrhenius constant written relative to a reference temperature, an exponent that is a
+    polynomial in T, 1/T and log T, one that does not decompose, and (optionally) an exp of the composition - the small
+    one-workgroup geometry (64 x 1, 20 nodes: the reference's own mesh) with whatever n2.kcache_choice picks, and the
+    equilibrium-type constant forced into the cache where the mechanism allows the small exp table."""
+    E, n = 5, 20
+    rows, named, inputs = [], [], []
+    mech = plan.Mechanism(INP.ch4_arrhenius_input(composition_exp=composition_exp))
+    for e in range(E):
+        mi = INP.ch4_arrhenius_input(composition_exp=composition_exp)
+        mi["operating-conditions"]["temperature"] = 940.0 + 15.0*e
+        nm, row = plan.member_constants(mi, mech, n)
+        rows.append(row), named.append(nm), inputs.append(mi)
+    rows, IV = np.array(rows), np.array([plan.initial_state(nm, mech, n) for nm in named])
+
+    def run(**kw):
+        dev = N2Device(mech, rows, n, **kw)
+        y = dev.to_device(IV)
+        dev.rk4(y, 2e-5, 400)
+        out = (y.cpu().numpy(), dev.status().copy(), dict(dev.defines), dev.fallbacks())
+        dev.close()
+        return out
+    got, flags, defs, fb = run()
+    assert defs.get("RMT_KCACHE") == "1" and defs.get("RMT_KCACHE_GEN") == "0" and not flags.any() and fb == 0
+    plain, pflags, pdefs, _ = run(defines={"RMT_KCACHE": "0"})
+    assert pdefs["RMT_KCACHE"] == "0" and not pflags.any()
+    V = mech.V
+    scale = np.max(np.abs(plain.reshape(E, V, n)), axis=2, keepdims=True)
+    assert np.max(np.abs(got - plain).reshape(E, V, n)/scale) < 2e-13
+    pr = O.setup_n2(inputs[E - 1], n)
+    want = O.rk4(0.0, 400*2e-5, 400, pr["IV"], O.make_rhs_vec(pr), keep=False)
+    sc = np.max(np.abs(want.reshape(V, n)), axis=1, keepdims=True)
+    assert np.max(np.abs(got[E - 1].reshape(V, n) - want.reshape(V, n))/sc) < 1e-11
+    # the decomposable exponent in the cache too (two-slot form: this mechanism cannot keep the small exp table)
+    two, tflags, tdefs, tfb = run(defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "1", "RMT_KC_REFRESH": "8"})
+    assert tdefs["RMT_KCACHE_GEN"] == "1" and not tflags.any() and tfb == 0
+    assert np.max(np.abs(two - plain).reshape(E, V, n)/scale) < 2e-13

@@ -717,6 +717,55 @@ def test_kcache_basis_decomposition_of_the_equilibrium_constants():
     assert syn.kcache_slots("basis") == syn.kcache_slots(False) == 9 and syn.kcache_small_exp("basis")
 
 
+def test_kcache_plans_of_a_mechanism_with_every_kind_of_exponent():
+    """Arrhenius -> "lin", polynomial / log exponent -> "basis", exp(-sqrt(T)/40) does not decompose and stays out of the
+    cache under the "basis" policy (two slots under policy True), an exp of the composition is never a root: with it the
+    caching kernel must keep the big exp table (no RMT_KC_SMALL_EXP, hence no equilibrium constants in the cache)."""
+    from rmt_app_amd.n2 import kcache_choice
+    for comp in (True, False):
+        mech = plan.Mechanism(INP.ch4_arrhenius_input(composition_exp=comp))
+        dag = mech.device_dag()
+        p = dag.kcache_plan("basis")
+        kinds = sorted(k if isinstance(k, str) else k[0] for k in p["kind"].values())
+        assert kinds == ["basis", "lin", "log"] and p["outside_exp"]         # (the sqrt exponent is outside either way)
+        assert sorted(k if isinstance(k, str) else k[0] for k in dag.kcache_plan(True)["kind"].values()) == \
+            ["gen", "gen", "lin", "log"]
+        assert not mech.kcache_small_exp("basis")
+        defs, lds = kcache_choice(mech, 20, False, 64, 1, None, None)
+        assert defs == {"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0", "RMT_KC_REFRESH": "8"} and lds is None
+        src = mech.source(hipbind_template(), block=64, npt=1, defines=defs)
+        assert "#define RMT_KC_SLOTS 3" in src                                 # 1/T_ref, the Arrhenius constant, log T_ref
+        with pytest.raises(ValueError):
+            from rmt_app_amd.n2 import device_source
+            _, row = plan.member_constants(INP.ch4_arrhenius_input(composition_exp=comp), mech, 20)
+            device_source(mech, row, 20, block=64, npt=1, defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "2",
+                                                                    "RMT_KC_SMALL_EXP": "1"})
+
+
+def test_kcache_basis_decomposition_random_exponents():
+    """lowering's basis decomposition against the DAG's own evaluation for random exponents a/T + b ln T + c T + d T^2 +
+    e/T^2 + f T^3 (written in different algebraic forms: products, quotients, powers, nested sums)."""
+    rng = np.random.default_rng(20260412)
+    for trial in range(12):
+        c = rng.normal(size=7)*np.array([3000.0, 4.0, 2e-3, 3e-6, 5e4, 4e-9, 1.0])
+        forms = [      # (the logarithm is handed in: the tracer rebinds `math` in the rate lambda itself only)
+            lambda T, c, log: c[0]/T + c[1]*log(T) + c[2]*T + c[3]*T**2 + c[4]/T**2 + c[5]*T*T*T + c[6],
+            lambda T, c, log: (c[0] + c[2]*T*T)/T + log(T)*c[1] - (-c[3])*(T*T) + c[4]*(1.0/T)**2 + (c[5]*T)*T**2 + c[6],
+            lambda T, c, log: ((c[0] + c[4]/T)/T + c[6]) + (c[1]*log(T) + T*(c[2] + T*(c[3] + T*c[5]))),
+        ]
+        F = forms[trial % 3]
+        f = lambda T, F=F, c=c: F(T, c, math.log)
+        low = lowering.trace({}, {"r1": lambda x, F=F, c=c: math.exp(F(x['T'], c, math.log))}, 1)
+        if trial % 2:
+            low = low.optimize()                  # the device build's strength-reduced DAG decomposes as well
+        p = low.kcache_plan("basis")
+        (r,) = [r for r in p["roots"] if isinstance(p["kind"][r], tuple) and p["kind"][r][0] == "basis"]
+        T1, T2 = 480.0 + 20.0*trial, 480.0 + 20.0*trial + 0.05
+        d = sum(cf*((math.log(T2) - math.log(T1)) if key == ("log",) else (T2**key[1] - T1**key[1]))
+                for key, cf in p["kind"][r][1].items())
+        assert abs(d - (f(T2) - f(T1))) < 1e-12*max(1.0, abs(f(T1))), (trial, d, f(T2) - f(T1))
+
+
 def hipbind_template():
     from rmt_app_amd import hipbind
     return hipbind.kernel_template()

@@ -261,6 +261,7 @@ extern "C" int rmt_n2_create(const rmt_n2_plan* p, rmt_n2_handle** out) {
 extern "C" void rmt_n2_destroy(rmt_n2_handle* h) {
     if (!h) return;
     DeviceGuard guard_(h);
+    if (h->fb_pending && h->ev_fb) (void)hipEventSynchronize(h->ev_fb);       // the counter copy into fb_host has landed
     if (h->d_members) (void)hipFree(h->d_members);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_work) (void)hipFree(h->d_work);

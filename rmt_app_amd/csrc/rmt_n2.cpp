@@ -398,6 +398,14 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&dt, (void*)&ns,
                         (void*)&h->d_flags};
         if (!h->f_rk4_redo) return launch(h, h->f_rk4_reg, args);
+        // (a stream that is being captured into a graph gets the two kernels and nothing else: the policy below reads an
+        // event and copies to host memory, which belongs to the time of execution, not of capture)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (h->stream && hipStreamIsCapturing(h->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+            HIP_OK(hipModuleLaunchKernel(h->f_rk4_reg, (unsigned)h->E, 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args, nullptr));
+            HIP_OK(hipModuleLaunchKernel(h->f_rk4_redo, (unsigned)h->E, 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args, nullptr));
+            return 0;
+        }
         // a caching code object.  Did the last cached launch lose half of its reactors to the plain stepper (a transient
         // faster than the cache's range serves)?  Then the cached stepper would only be run in vain for a while.
         if (h->fb_pending && hipEventQuery(h->ev_fb) == hipSuccess) {

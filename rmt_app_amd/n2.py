@@ -829,7 +829,7 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
         check = False
         for lo in range(0, tNo, batch):
             hi = min(tNo, lo + batch)
-            hosts, counters = [], []
+            hosts, counters, landed = [], [], []
             for i in range(lo, hi):
                 t0, t1 = float(opTSpan[i]), float(opTSpan[i + 1])
                 _progress(i + 1, tNo + 1, quiet)
@@ -842,14 +842,18 @@ def integrate_intervals(dev, y, cfg, ivp, opTSpan, n_members, zNo, quiet, on_int
                     c = torch.empty(dev._stats.shape, dtype=dev._stats.dtype, pin_memory=True)
                     c.copy_(dev._stats, non_blocking=True)
                     counters.append(c)
-            dev.raise_on_flags()                                  # (synchronises the stream)
-            for k, i in enumerate(range(lo, hi)):
+                ev = torch.cuda.Event()
+                ev.record()
+                landed.append(ev)
+            for k, i in enumerate(range(lo, hi)):                 # packing interval i while the device is at i+1, i+2, ...
+                landed[k].synchronize()
                 if adaptive:
                     raw = counters[k].numpy()
                     acc, rej = raw[:, 2].copy().view(np.int64), raw[:, 3].copy().view(np.int64)
                     stats["accepted"] = acc if stats["accepted"] is None else stats["accepted"] + acc
                     stats["rejected"] = rej if stats["rejected"] is None else stats["rejected"] + rej
                 on_interval(i, float(opTSpan[i + 1]), hosts[k].numpy().astype(np.float64))
+            dev.raise_on_flags()                                  # (sticky status words: whatever a launch of the batch flagged)
         return finish_stats(stats, ivp, n_members, tNo, zNo, dev.jacobian_evals)
 
     for i in range(tNo):

@@ -111,7 +111,7 @@ def rk45_geometry(V, N, fp32=False, chain=True, E=None):
 
 
 KC_REFRESH = 8          # csrc/kernels/50_rk4.inc RMT_KC_REFRESH: the cache's reference point moves every 8th step ...
-KC_MAX_AGE = 1.7e-5     # ... RMT_KC_MAX_AGE: or sooner, so that no reference point is older than this much model time [s]
+KC_MAX_AGE = 1.3e-5     # ... RMT_KC_MAX_AGE: or sooner, so that no reference point is older than this much model time [s]
 
 
 def kc_period(defines, dt):

@@ -209,11 +209,11 @@ def test_a_launch_that_loses_its_reactors_switches_the_next_ones_to_the_plain_st
 
 
 def test_refresh_period_follows_the_step_size():
-    """n2.kc_period = the kernel's rule: at most RMT_KC_REFRESH steps and no reference point older than 17 us of model
+    """n2.kc_period = the kernel's rule: at most RMT_KC_REFRESH steps and no reference point older than 13 us of model
     time; a large step (one refresh per step) and the default one give the plain stepper's result."""
     from rmt_app_amd.n2 import kc_period
     d = {"RMT_KC_REFRESH": "8"}
-    assert [kc_period(d, dt) for dt in (2e-6, 2.5e-6, 5e-6, 1e-5, 1e-4)] == [8, 6, 3, 1, 1] and kc_period({}, 2e-6) == 1
+    assert [kc_period(d, dt) for dt in (1e-6, 2e-6, 2.5e-6, 5e-6, 1e-5, 1e-4)] == [8, 6, 5, 2, 1, 1] and kc_period({}, 2e-6) == 1
     mech, rows, IV, _ = _sweep(3)
     for dt, steps in ((1e-6, 200), (4e-6, 60)):
         got, flags, _ = _run(mech, rows, IV, steps, dt=dt)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """How often does the cached on-chip RK4 stepper fall back to its plain twin during the START-UP of the bench sweep
 (256 reactors x 1024 nodes from the reference's initial state: bed at the feed composition and temperature), for
-different refresh intervals of the cache's reference point (RMT_KC_REFRESH)?  usage: kcache_transient.py [K ...]"""
+different refresh intervals of the cache's reference point (RMT_KC_REFRESH)?  usage: kcache_transient.py [K ...]
+FIRST=<member index> in the environment picks another rank's block of the 2048-member sweep (hotter inlets)."""
 import os
 import sys
 import time
@@ -17,11 +18,13 @@ from rmt_app_amd.n2 import N2Device        # noqa: E402
 import torch                               # noqa: E402
 
 E, N, STEPS, LAUNCHES = 256, 1024, 250, 40
-inputs = B.sweep_member_inputs(0, E, total=2048)
+FIRST = int(os.environ.get("FIRST", 0))
+inputs = B.sweep_member_inputs(FIRST, E, total=2048)
 mech = plan.Mechanism(inputs[0])
 pairs = [plan.member_constants(mi, mech, N) for mi in inputs]
 rows = np.array([r for _, r in pairs])
 IV = np.array([plan.initial_state(nm, mech, N) for nm, _ in pairs])
+print("members %d..%d of the sweep" % (FIRST, FIRST + E - 1))
 print("| refresh K | launches x steps | fallbacks per launch (first 10) | total fallbacks | wall ms | max dT/dt seen K/s |")
 print("|---|---|---|---|---|---|")
 for K in [int(a) for a in sys.argv[1:]] or [1, 4, 8, 16]:

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 3, batch S: (timing only, wrong results) what caching the three equilibrium constants with polynomial exponents
+# (historical: the stand-in switch RMT_TIMING_GEN_CHEAP was removed from the lowering after this measurement)
 # as well would be worth - their exp replaced by a two-instruction stand-in - and the merged node reciprocals
 mkdir -p gpurun_out/r3s
 L=gpurun_out/r3s/log.txt

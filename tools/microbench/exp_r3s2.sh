@@ -1,5 +1,6 @@
 #!/bin/bash
 # batch S, second half: the same under rocprofv3 --kernel-trace --stats, to read the duration of rmt_n2_rk4_reg alone
+# (historical: the stand-in switch RMT_TIMING_GEN_CHEAP was removed from the lowering after this measurement)
 # (with the stand-in the reactors leave the cache's range and the redo kernel integrates them again)
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/r3s

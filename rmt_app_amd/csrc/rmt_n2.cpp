@@ -383,6 +383,35 @@ extern "C" int rmt_n2_rhs(rmt_n2_handle* h, double t, const void* y, void* dydt)
 
 static bool fits_registers(const rmt_n2_handle* h) { return h->N <= h->block * h->npt; }
 
+// Caching RK4 steppers: did the last cached launch lose at least half of its reactors to the plain stepper (a transient
+// faster than the cache's range serves)?  Then the cached pass would only be run in vain for a while: true = this call
+// runs the plain stepper alone.  The counter behind the status words is copied back behind every cached launch (pinned
+// word + event, never waited for).
+static bool plain_this_call(rmt_n2_handle* h) {
+    if (h->fb_pending && hipEventQuery(h->ev_fb) == hipSuccess) {
+        h->fb_pending = false;
+        const unsigned lost = h->fb_host[0] - h->fb_seen;
+        h->fb_seen = h->fb_host[0];
+        if (2u * lost >= (unsigned)h->E) h->plain_left = RMT_N2_PLAIN_LAUNCHES;
+    }
+    if (h->plain_left <= 0) return false;
+    --h->plain_left;
+    return true;
+}
+
+static int copy_back_fallbacks(rmt_n2_handle* h) {
+    if (h->fb_pending) return 0;
+    HIP_OK(hipMemcpyAsync(h->fb_host, h->d_flags + h->E, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipEventRecord(h->ev_fb, h->stream));
+    h->fb_pending = true;
+    return 0;
+}
+
+static bool capturing(rmt_n2_handle* h) {      // (the policy reads an event and copies to host memory: not under capture)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    return h->stream && hipStreamIsCapturing(h->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+}
+
 extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64_t nsteps) {
     (void)t0;
     if (!h || !y) return fail("null argument");
@@ -398,38 +427,20 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&dt, (void*)&ns,
                         (void*)&h->d_flags};
         if (!h->f_rk4_redo) return launch(h, h->f_rk4_reg, args);
-        // (a stream that is being captured into a graph gets the two kernels and nothing else: the policy below reads an
-        // event and copies to host memory, which belongs to the time of execution, not of capture)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (h->stream && hipStreamIsCapturing(h->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        // (a stream that is being captured into a graph gets the two kernels and nothing else)
+        if (capturing(h)) {
             HIP_OK(hipModuleLaunchKernel(h->f_rk4_reg, (unsigned)h->E, 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args, nullptr));
             HIP_OK(hipModuleLaunchKernel(h->f_rk4_redo, (unsigned)h->E, 1, 1, (unsigned)h->block, 1, 1, 0, h->stream, args, nullptr));
             return 0;
         }
-        // a caching code object.  Did the last cached launch lose half of its reactors to the plain stepper (a transient
-        // faster than the cache's range serves)?  Then the cached stepper would only be run in vain for a while.
-        if (h->fb_pending && hipEventQuery(h->ev_fb) == hipSuccess) {
-            h->fb_pending = false;
-            const unsigned lost = h->fb_host[0] - h->fb_seen;
-            h->fb_seen = h->fb_host[0];
-            if (2u * lost >= (unsigned)h->E) {
-                h->plain_left = RMT_N2_PLAIN_LAUNCHES;
-                HIP_OK(hipMemsetAsync(h->d_flags + h->E + 1, 1, sizeof(unsigned), h->stream));
-            }
-        }
-        if (h->plain_left > 0) {
+        if (plain_this_call(h)) {        // flags[E + 1] != 0: rmt_n2_rk4_reg_redo integrates every reactor
+            HIP_OK(hipMemsetAsync(h->d_flags + h->E + 1, 1, sizeof(unsigned), h->stream));
             const int rc = launch(h, h->f_rk4_redo, args);
-            if (--h->plain_left == 0)
-                HIP_OK(hipMemsetAsync(h->d_flags + h->E + 1, 0, sizeof(unsigned), h->stream));
+            HIP_OK(hipMemsetAsync(h->d_flags + h->E + 1, 0, sizeof(unsigned), h->stream));
             return rc;
         }
         if (launch(h, h->f_rk4_reg, args, -1, 1, 0, h->f_rk4_redo)) return 1;
-        if (!h->fb_pending) {
-            HIP_OK(hipMemcpyAsync(h->fb_host, h->d_flags + h->E, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-            HIP_OK(hipEventRecord(h->ev_fb, h->stream));
-            h->fb_pending = true;
-        }
-        return 0;
+        return copy_back_fallbacks(h);
     }
     // chained workgroups: C chunks per reactor, T teams, every workgroup resident (T*C <= #CUs)
     const int W = h->block * h->npt;
@@ -463,6 +474,15 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
             falt = h->d_redo + h->E;
             HIP_OK(hipMemsetAsync(h->d_redo, 0, 2 * (size_t)h->E * sizeof(unsigned), h->stream));
         }
+        // the same policy as for the one-workgroup stepper: after a launch that lost half of its reactors the plain
+        // chained stepper runs alone for a while - every redo word set (to a value the fallback counter does not count),
+        // the input copied to the backup buffer the plain stepper reads
+        const bool plain = h->f_rk4_chain_redo && !capturing(h) && plain_this_call(h);
+        if (plain) {
+            const size_t state = (size_t)h->E * h->V * h->N * (h->fp32 ? 4 : 8);
+            HIP_OK(hipMemcpyAsync(h->d_backup, y, state, hipMemcpyDeviceToDevice, h->stream));
+            HIP_OK(hipMemsetAsync(h->d_redo, 2, (size_t)h->E * sizeof(unsigned), h->stream));
+        }
         unsigned long long* decision = nullptr;
         unsigned* abort_words = nullptr;
         void* args[] = {(void*)&y, (void*)&h->d_members, (void*)&N, (void*)&E, (void*)&C, (void*)&T,
@@ -471,7 +491,7 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
         h->last_chunks = C;
         h->last_teams = T;
         HIP_OK(hipEventRecord(h->ev0, h->stream));
-        for (hipFunction_t f : {h->f_rk4_chain, h->f_rk4_chain_redo}) {
+        for (hipFunction_t f : {plain ? (hipFunction_t) nullptr : h->f_rk4_chain, h->f_rk4_chain_redo}) {
             if (!f) continue;
             HIP_OK(hipMemsetAsync(h->d_sync, 0, links * 32 * sizeof(unsigned long long), h->stream));
             if (ensure_rings(h, T, C, &decision, &abort_words)) return 1;        // (clears the rings)
@@ -479,6 +499,7 @@ extern "C" int rmt_n2_rk4(rmt_n2_handle* h, void* y, double t0, double dt, int64
         }
         HIP_OK(hipEventRecord(h->ev1, h->stream));
         h->timed = true;
+        if (h->f_rk4_chain_redo && !plain && !capturing(h)) return copy_back_fallbacks(h);
         return 0;
     }
     if (ensure_work(h, 3)) return 1;

@@ -261,3 +261,27 @@ def test_mechanism_with_every_kind_of_exponent_cached_vs_plain_and_oracle(compos
     two, tflags, tdefs, tfb = run(defines={"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "1", "RMT_KC_REFRESH": "8"})
     assert tdefs["RMT_KCACHE_GEN"] == "1" and not tflags.any() and tfb == 0
     assert np.max(np.abs(two - plain).reshape(E, V, n)/scale) < 2e-13
+
+
+def test_chained_launch_that_loses_its_reactors_switches_the_next_ones_to_the_plain_stepper():
+    """The same host policy for the chained caching stepper: cached, 8 x the plain chained stepper alone (input copied to
+    the backup buffer, every redo word forced, not counted as fallbacks), cached again, ..."""
+    import torch
+    E = 4
+    mech, rows, IV, _ = _chain_sweep(E)
+    dev = N2Device(mech, rows, NC, block=512, npt=2, lds_state=1,
+                   defines={"RMT_KCACHE_CHAIN": "1", "RMT_KCACHE_GEN": "0", "RMT_KCACHE_THR": "1e-12"})
+    dev.set_mode("chain")
+    y = dev.to_device(IV)
+    counts = []
+    for _ in range(12):
+        dev.rk4(y, 2e-6, 5)
+        torch.cuda.synchronize()
+        counts.append(dev.fallbacks())
+    assert counts == [E]*9 + [2*E]*3, counts
+    assert not dev.status().any()
+    got = y.cpu().numpy()
+    dev.close()
+    plain, pflags, _ = _run_chain(mech, rows, IV, 60, defines={"RMT_KCACHE_CHAIN": "0"}, lds_state=1)
+    assert not pflags.any()
+    np.testing.assert_array_equal(got, plain)

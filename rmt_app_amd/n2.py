@@ -125,7 +125,7 @@ def kc_period(defines, dt):
 def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     """(defines, lds_state) with the RK4 steppers' cache of the temperature-only rate constants switched on where it has
     been measured to pay (csrc/kernels/50_rk4.inc rmt_rk4_reg_body / rmt_rk4_chain_body; profiles/round3_kcache.md), model
-    N2 in fp64 with at most 8 variables per node:
+    N2 in fp64 (the list is for at most 8 variables per node; wider mechanisms: see the table in the body):
 
     * one workgroup per reactor at 512 x 2 (RMT_KCACHE; the bench shape, 1.62e10 -> 1.95e10 node-steps/s) and at the
       small geometries of short reactors (2048 x 20 nodes at 64 x 1: 3.2e9 -> 5.0e9, 2048 x 128 at 128 x 1: 1.21e10 ->
@@ -143,23 +143,30 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     defs = dict(defines or {})
     chained = int(N) > int(block)*int(npt)
     key = "RMT_KCACHE_CHAIN" if chained else "RMT_KCACHE"
-    wide = (int(block), int(npt)) == (512, 2)                 # two waves per SIMD at the register limit: y_n has to move
-    if key in defs or fp32 or getattr(mech, "model", "N2") != "N2" or mech.V > 8 or int(npt) > 2:
+    geo = (int(block), int(npt))
+    if key in defs or fp32 or getattr(mech, "model", "N2") != "N2":
         return defs, lds_state
+    # where the cache measured faster (profiles/round3_kcache.md) -> the lds_state it needs (None: the geometry's default).
+    # At most 8 variables per node (DME): every chained geometry; one workgroup per reactor at 512 x 2 and at 64 / 128 /
+    # 256 threads (512 x 1: SLOWER, 1.54e10 -> 1.39-1.48e10).  Wider mechanisms (12 species, V = 13): 64 x 1 (8.7e9 ->
+    # 1.21e10), 512 x 1 (1.07e10 -> 1.16e10) and the chained 512 x 1 (9.9e9 -> 1.04e10), with y_n in LDS; 128 x 1 is
+    # SLOWER there (8.8e9 -> 7.1e9).
+    if mech.V <= 8:
+        good = {geo: (1 if geo == (512, 2) else lds_state)} if chained and geo[1] <= 2 else \
+            {(512, 2): 1, (64, 1): lds_state, (128, 1): lds_state, (256, 1): lds_state}
+    else:
+        good = {(512, 1): 1} if chained else {(64, 1): lds_state, (512, 1): 1}
+    if geo not in good or (good[geo] == 1 and lds_state not in (None, 1)):
+        return defs, lds_state
+    want = good[geo]
     if chained:
-        want = 1 if wide else lds_state
-        if (wide and lds_state not in (None, 1)) or not mech.kcache_fits_chain(fp32, block, npt, want, gen=False):
+        if not mech.kcache_fits_chain(fp32, block, npt, want, gen=False):
             return defs, lds_state
         defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
         return defs, want
-    # one workgroup per reactor: 512 x 2 and the small geometries of short reactors (block <= 256, one node per lane);
-    # 512 x 1 measured SLOWER with the cache (1.54e10 -> 1.39-1.48e10) and stays plain
-    if not (wide or (int(npt) == 1 and int(block) <= 256)) or (wide and lds_state not in (None, 1)):
-        return defs, lds_state
-    want = 1 if wide else lds_state
     # equilibrium constants too where that measured faster: everywhere but at 128 threads (1.53e10 with the Arrhenius
     # constants alone against 1.39e10 - the wider kernel loses a wave of occupancy there)
-    if int(block) != 128 and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
+    if geo[0] != 128 and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
             and mech.kcache_fits(fp32, block, npt, want, gen="basis", small_exp=True, node_major=True):
         # (a node's slots side by side in LDS: one address register per node; with slot-major rows of 8 KiB the far slots
         # need registers of their own and the 512 x 2 step loop spills - 1.86e10 against 1.95e10 node-steps/s)

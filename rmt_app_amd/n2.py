@@ -147,13 +147,13 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     if key in defs or fp32 or getattr(mech, "model", "N2") != "N2":
         return defs, lds_state
     # where the cache measured faster (profiles/round3_kcache.md) -> the lds_state it needs (None: the geometry's default).
-    # At most 8 variables per node (DME): every chained geometry; one workgroup per reactor at 512 x 2 and at 64 / 128 /
-    # 256 threads (512 x 1: SLOWER, 1.54e10 -> 1.39-1.48e10).  Wider mechanisms (12 species, V = 13): 64 x 1 (8.7e9 ->
+    # At most 8 variables per node (DME): every chained geometry; one workgroup per reactor at 512 x 2, at 64 / 128 / 256
+    # threads and at 512 x 1 with y_n in LDS (1.52e10 -> 1.72e10; with the geometry's own lds_state it is SLOWER).  Wider mechanisms (12 species, V = 13): 64 x 1 (8.7e9 ->
     # 1.21e10), 512 x 1 (1.07e10 -> 1.16e10) and the chained 512 x 1 (9.9e9 -> 1.04e10), with y_n in LDS; 128 x 1 is
     # SLOWER there (8.8e9 -> 7.1e9).
     if mech.V <= 8:
         good = {geo: (1 if geo == (512, 2) else lds_state)} if chained and geo[1] <= 2 else \
-            {(512, 2): 1, (64, 1): lds_state, (128, 1): lds_state, (256, 1): lds_state}
+            {(512, 2): 1, (64, 1): lds_state, (128, 1): lds_state, (256, 1): lds_state, (512, 1): 1}
     else:
         good = {(512, 1): 1} if chained else {(64, 1): lds_state, (512, 1): 1}
     if geo not in good or (good[geo] == 1 and lds_state not in (None, 1)):
@@ -164,9 +164,9 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
             return defs, lds_state
         defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
         return defs, want
-    # equilibrium constants too where that measured faster: everywhere but at 128 threads (1.53e10 with the Arrhenius
-    # constants alone against 1.39e10 - the wider kernel loses a wave of occupancy there)
-    if geo[0] != 128 and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
+    # equilibrium constants too where that measured faster: everywhere but at 128 x 1 (1.53e10 with the Arrhenius
+    # constants alone against 1.39e10 - the wider kernel loses a wave of occupancy there) and 512 x 1 (1.72e10 against 1.52e10)
+    if geo not in ((128, 1), (512, 1)) and mech.kcache_small_exp("basis") and mech.kcache_slots("basis") > mech.kcache_slots(False) \
             and mech.kcache_fits(fp32, block, npt, want, gen="basis", small_exp=True, node_major=True):
         # (a node's slots side by side in LDS: one address register per node; with slot-major rows of 8 KiB the far slots
         # need registers of their own and the 512 x 2 step loop spills - 1.86e10 against 1.95e10 node-steps/s)

@@ -144,8 +144,18 @@ def kcache_choice(mech, N, fp32, block, npt, lds_state, defines):
     chained = int(N) > int(block)*int(npt)
     key = "RMT_KCACHE_CHAIN" if chained else "RMT_KCACHE"
     geo = (int(block), int(npt))
-    if key in defs or fp32 or getattr(mech, "model", "N2") != "N2":
+    model = getattr(mech, "model", "N2")
+    if key in defs or fp32 or model not in ("N2", "M2"):
         return defs, lds_state
+    if model == "M2":
+        # the dimensional model: its one-workgroup stepper at 512 x 2 (which keeps y_n in LDS anyway), Arrhenius constants
+        # only - with the equilibrium constants its step loop spills (28 scratch accesses)
+        if chained or geo != (512, 2) or lds_state not in (None, 1) or mech.V > 8 \
+                or not mech.kcache_fits(fp32, block, npt, 1, gen=False):
+            return defs, lds_state
+        defs.update({key: "1", "RMT_KCACHE_GEN": "0"})
+        defs.setdefault("RMT_KC_REFRESH", str(KC_REFRESH))
+        return defs, 1
     # where the cache measured faster (profiles/round3_kcache.md) -> the lds_state it needs (None: the geometry's default).
     # At most 8 variables per node (DME): every chained geometry; one workgroup per reactor at 512 x 2, at 64 / 128 / 256
     # threads and at 512 x 1 with y_n in LDS (1.52e10 -> 1.72e10; with the geometry's own lds_state it is SLOWER).  Wider mechanisms (12 species, V = 13): 64 x 1 (8.7e9 ->

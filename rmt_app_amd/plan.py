@@ -263,7 +263,7 @@ class Mechanism:
         """LDS bytes of a caching RK4 stepper: `state_vectors` of its long-lived vectors, the cache, the exp table (16 KiB;
         512 B in the small form a caching kernel may keep, and for one-wave workgroups) and the exchange buffers."""
         slots = self.kcache_slots(gen)
-        if not slots or fp32 or self.model != "N2":
+        if not slots or fp32 or self.model not in ("N2", "M2"):
             return None
         table = 512 if (small_exp or block <= 64) else 16384
         nodes = block*npt

@@ -285,3 +285,37 @@ def test_chained_launch_that_loses_its_reactors_switches_the_next_ones_to_the_pl
     plain, pflags, _ = _run_chain(mech, rows, IV, 60, defines={"RMT_KCACHE_CHAIN": "0"}, lds_state=1)
     assert not pflags.any()
     np.testing.assert_array_equal(got, plain)
+
+
+def test_model_m2_cached_stepper_matches_plain_and_oracle():
+    """The dimensional dynamic model (pbReactor.py:845-1165) through the same caching on-chip stepper: against its plain
+    twin and against the M2 oracle's RK4."""
+    from oracle import m2_oracle as OM
+    E, n = 4, 1024
+    mech = plan.Mechanism(INP.m2_dme_input())
+    rows, IVs, inputs = [], [], []
+    for e in range(E):
+        mi = INP.m2_dme_input()
+        mi["operating-conditions"]["temperature"] = 510.0 + 8.0*e
+        nm, row = plan.member_constants_m2(mi, mech, n)
+        rows.append(row), IVs.append(plan.initial_state_m2(nm, mech, n)), inputs.append(mi)
+    rows, IV = np.array(rows), np.array(IVs)
+
+    def run(**kw):
+        dev = N2Device(mech, rows, n, block=512, npt=2, **kw)
+        y = dev.to_device(IV)
+        dev.rk4(y, 2e-6, 120)
+        out = (y.cpu().numpy(), dev.status().copy(), dict(dev.defines), dev.fallbacks())
+        dev.close()
+        return out
+    got, flags, defs, fb = run()
+    assert defs.get("RMT_KCACHE") == "1" and defs.get("RMT_KCACHE_GEN") == "0" and not flags.any() and fb == 0
+    plain, pflags, pdefs, _ = run(defines={"RMT_KCACHE": "0"})
+    assert pdefs["RMT_KCACHE"] == "0" and not pflags.any()
+    V = mech.V
+    scale = np.max(np.abs(plain.reshape(E, V, n)), axis=2, keepdims=True)
+    assert np.max(np.abs(got - plain).reshape(E, V, n)/scale) < 2e-13
+    pr = OM.setup_m2(inputs[E - 1], n)
+    want = O.rk4(0.0, 120*2e-6, 120, pr["IV"], OM.make_rhs_vec(pr), keep=False)
+    sc = np.max(np.abs(want.reshape(V, n)), axis=1, keepdims=True)
+    assert np.max(np.abs(got[E - 1].reshape(V, n) - want.reshape(V, n))/sc) < 1e-10

@@ -793,7 +793,9 @@ def test_kcache_choice_and_the_code_object_it_builds():
     assert kcache_choice(dme, 1024, False, 1024, 1, None, None) == ({}, None)           # one workgroup, another geometry
     assert kcache_choice(plan.Mechanism(INP.syn12_input()), 1024, False, 256, 2, None, None) == ({}, None)      # V = 13
     assert kcache_choice(plan.Mechanism(INP.ch4_input()), 1024, False, 512, 2, None, None) == ({}, None)   # nothing to cache
-    assert kcache_choice(plan.Mechanism(INP.m2_dme_input()), 1024, False, 512, 2, None, None) == ({}, None)
+    m2 = plan.Mechanism(INP.m2_dme_input())                                             # model M2: 512 x 2 only, Arrhenius constants
+    assert kcache_choice(m2, 1024, False, 512, 2, None, None) == ({"RMT_KCACHE": "1", "RMT_KCACHE_GEN": "0", "RMT_KC_REFRESH": "8"}, 1)
+    assert kcache_choice(m2, 4096, False, 512, 2, None, None) == ({}, None) and kcache_choice(m2, 100, False, 128, 1, None, None) == ({}, None)
     _, row = plan.member_constants(INP.dme_notebook_input(), dme, 1024)
     block, npt, defs, src, key = device_source(dme, np.tile(row, (256, 1)), 1024)
     assert (block, npt) == (512, 2) and defs["RMT_KCACHE"] == "1" and "#define RMT_LDS_STATE 1" in src

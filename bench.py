@@ -536,6 +536,9 @@ def main():
     flags = dev.status()
     if flags.any():
         raise SystemExit("device flags set during the bench: %s" % flags[flags != 0][:4])
+    # reactor-launches the caching stepper handed to its plain twin (warm-up + timed region): 0 = every timed launch was
+    # the cached kernel alone, nothing was integrated twice
+    fallbacks = dev.fallbacks()
     tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
     if distributed:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -591,7 +594,8 @@ def main():
                                   "solution)" if (world == 1 and not args.no_cpu_baseline) else
                                   "throughput line only (the extra measurements run at N = 1)"),
                        "kernel": "%s block=%d npt=%d lds_state=%d" % (kname, dev.block, dev.npt, dev.lds_state),
-                       "kernel_digest": ist["kernel_digest"], "code_object_digest": ist["digest"]},
+                       "kernel_digest": ist["kernel_digest"], "code_object_digest": ist["digest"],
+                       "cache_fallbacks_rank0": fallbacks},
             # contract form: ALGORITHMIC bytes (2(S+2)8 B per node-step) / kernel time against the
             # HBM peak.  The state stays on chip for all steps of a launch, so this is NOT the kernel's HBM
             # use (that is `measured_hbm_GBs` = PMC traffic / kernel time, ~1000x smaller) and 1/frac is not

@@ -238,11 +238,23 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
     return block, npt, defs, src, key
 
 
+def compile_options(block, npt, features=(), extra_opts=""):
+    """hipRTC options beyond the library's own (csrc/rmt_n2.cpp rmt_n2_compile) for a code object of this geometry.  The
+    RK4 steppers at 512 x 2 - two waves per SIMD at the register limit - are scheduled with LLVM's AMDGPU register
+    pressure trackers (`-amdgpu-use-amdgpu-trackers=1`): bench 2.018e10 -> 2.045e10 node-steps/s, chained 256 x 4096
+    nodes 1.53e10 -> 1.58e10; the stiff stepper (-1.5 %) and the small chunks of ONE long reactor (-1.9 %) are SLOWER
+    with it, RK45 unchanged (tools/microbench/exp_r3ae.sh), so nothing else gets it."""
+    auto = "-mllvm -amdgpu-use-amdgpu-trackers=1" if (int(block), int(npt)) == (512, 2) and not features else ""
+    if not auto or "amdgpu-use-amdgpu-trackers" in (extra_opts or ""):
+        return extra_opts or ""
+    return ("%s %s" % (extra_opts, auto)).strip()
+
+
 def precompile(mech, members, N, arch="gfx950", extra_opts="", **kw):
     """Cross-compile (hipRTC, no GPU needed) the code object N2Device(mech, members, N, **kw) will load and
     leave it in the in-tree cache; returns its cache key."""
-    _, _, _, src, key = device_source(mech, members, N, **kw)
-    hipbind.compile_cached(src, key, arch, extra_opts)
+    block, npt, _, src, key = device_source(mech, members, N, **kw)
+    hipbind.compile_cached(src, key, arch, compile_options(block, npt, kw.get("features", ()), extra_opts))
     return key
 
 
@@ -277,7 +289,7 @@ class N2Device:
         self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         if code is None:      # an ensemble rank may receive rank 0's code object instead
-            code = hipbind.compile_cached(src, key, arch, extra_opts)
+            code = hipbind.compile_cached(src, key, arch, compile_options(self.block, self.npt, self.features, extra_opts))
         self._code = C.create_string_buffer(code, len(code))
         p = hipbind.Plan()
         p.abi_version = hipbind.ABI_VERSION
@@ -642,7 +654,8 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
     defines, lds_state = kcache_choice(mech, N, fp32, block, npt, lds_state, defines)
     tpl = hipbind.kernel_template()
     return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, lds_state, defines),
-                                  mech.digest(tpl, fp32, block, npt, lds_state, defines), arch, extra_opts)
+                                  mech.digest(tpl, fp32, block, npt, lds_state, defines), arch,
+                                  compile_options(block, npt, (), extra_opts))
 
 
 def resolve_ivp(ivp):

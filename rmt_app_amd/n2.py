@@ -9,6 +9,8 @@ torch is used only as the owner of device memory and streams.
 import ctypes as C
 from timeit import default_timer as timer
 
+import os
+
 import numpy as np
 
 from . import hipbind, plan
@@ -238,13 +240,18 @@ def device_source(mech, members, N, fp32=False, block=None, npt=None, lds_state=
     return block, npt, defs, src, key
 
 
-def compile_options(block, npt, features=(), extra_opts=""):
+def compile_options(block, npt, features=(), extra_opts="", defines=None):
     """hipRTC options beyond the library's own (csrc/rmt_n2.cpp rmt_n2_compile) for a code object of this geometry.  The
     RK4 steppers at 512 x 2 - two waves per SIMD at the register limit - are scheduled with LLVM's AMDGPU register
     pressure trackers (`-amdgpu-use-amdgpu-trackers=1`): bench 2.018e10 -> 2.045e10 node-steps/s, chained 256 x 4096
     nodes 1.53e10 -> 1.58e10; the stiff stepper (-1.5 %) and the small chunks of ONE long reactor (-1.9 %) are SLOWER
-    with it, RK45 unchanged (tools/microbench/exp_r3ae.sh), so nothing else gets it."""
-    auto = "-mllvm -amdgpu-use-amdgpu-trackers=1" if (int(block), int(npt)) == (512, 2) and not features else ""
+    with it, and so is the on-chip RK45 stepper on the bench sweep (6.90e9 -> 6.71e9; tools/microbench/exp_r3ae.sh,
+    rk45_ab.py): code objects with optional kernel families or built for RK45 (rk45_geometry's "RMT_RK45_LDS") keep the
+    default."""
+    auto = "-mllvm -amdgpu-use-amdgpu-trackers=1" if ((int(block), int(npt)) == (512, 2) and not features
+                                                       and "RMT_RK45_LDS" not in (defines or {})) else ""
+    if os.environ.get("RMT_N2_NO_TRACKERS"):          # (A/B measurements)
+        auto = ""
     if not auto or "amdgpu-use-amdgpu-trackers" in (extra_opts or ""):
         return extra_opts or ""
     return ("%s %s" % (extra_opts, auto)).strip()
@@ -254,7 +261,8 @@ def precompile(mech, members, N, arch="gfx950", extra_opts="", **kw):
     """Cross-compile (hipRTC, no GPU needed) the code object N2Device(mech, members, N, **kw) will load and
     leave it in the in-tree cache; returns its cache key."""
     block, npt, _, src, key = device_source(mech, members, N, **kw)
-    hipbind.compile_cached(src, key, arch, compile_options(block, npt, kw.get("features", ()), extra_opts))
+    hipbind.compile_cached(src, key, arch, compile_options(block, npt, kw.get("features", ()), extra_opts,
+                                                           kw.get("defines")))
     return key
 
 
@@ -289,7 +297,8 @@ class N2Device:
         self.lds_state = mech.lds_state(self.fp32, self.block, self.npt, lds_state)
         arch = torch.cuda.get_device_properties(self.device).gcnArchName.split(":")[0]
         if code is None:      # an ensemble rank may receive rank 0's code object instead
-            code = hipbind.compile_cached(src, key, arch, compile_options(self.block, self.npt, self.features, extra_opts))
+            code = hipbind.compile_cached(src, key, arch, compile_options(self.block, self.npt, self.features, extra_opts,
+                                                                          self.defines))
         self._code = C.create_string_buffer(code, len(code))
         p = hipbind.Plan()
         p.abi_version = hipbind.ABI_VERSION
@@ -655,7 +664,7 @@ def compile_mechanism(mech, N, fp32=False, block=None, npt=None, lds_state=None,
     tpl = hipbind.kernel_template()
     return hipbind.compile_cached(mech.source(tpl, fp32, block, npt, lds_state, defines),
                                   mech.digest(tpl, fp32, block, npt, lds_state, defines), arch,
-                                  compile_options(block, npt, (), extra_opts))
+                                  compile_options(block, npt, (), extra_opts, defines))
 
 
 def resolve_ivp(ivp):

@@ -771,6 +771,23 @@ def hipbind_template():
     return hipbind.kernel_template()
 
 
+def test_refresh_period_and_compile_options_rules():
+    """Host rules that mirror the kernels': n2.kc_period (steps between two moves of the cache's reference point: at most
+    RMT_KC_REFRESH, and no reference point older than 13 us of model time) and n2.compile_options (the register-pressure
+    trackers for 512 x 2 code objects only - not with optional kernel families, not for RK45 builds, not twice)."""
+    from rmt_app_amd.n2 import compile_options, kc_period, rk45_geometry
+    d = {"RMT_KC_REFRESH": "8"}
+    assert [kc_period(d, dt) for dt in (1e-6, 2e-6, 2.5e-6, 5e-6, 1e-5, 1e-4)] == [8, 6, 5, 2, 1, 1]
+    assert kc_period({}, 2e-6) == 1 and kc_period({"RMT_KC_REFRESH": "4"}, 1e-6) == 4 and kc_period(d, 0.0) == 1
+    assert kc_period({"RMT_KC_REFRESH": "8", "RMT_KC_MAX_AGE": "4e-6"}, 2e-6) == 2
+    tr = "-mllvm -amdgpu-use-amdgpu-trackers=1"
+    assert compile_options(512, 2) == tr and compile_options(512, 2, (), "-O3") == "-O3 " + tr
+    assert compile_options(512, 2, ("ros4",)) == "" and compile_options(256, 1) == "" and compile_options(128, 1, (), "-g") == "-g"
+    assert compile_options(512, 2, (), tr) == tr
+    block, npt, defs = rk45_geometry(7, 1024, E=256)
+    assert (block, npt) == (512, 2) and compile_options(block, npt, (), "", defs) == ""
+
+
 def test_kcache_choice_and_the_code_object_it_builds():
     """n2.kcache_choice: the cache is switched on for the measured geometry only (512 x 2, model N2, fp64, a reactor that
     fits the workgroup), with y_n in LDS; an explicit RMT_KCACHE or another lds_state is left alone.  The code object then

@@ -824,6 +824,9 @@ def test_kcache_choice_and_the_code_object_it_builds():
         *device_source(dme, np.tile(row, (256, 1)), 1024, defines=extra)[3:5], "gfx950"))
     assert mix["valu"] < 3150 and mix["scratch"] == 0 and "refresh step" in note         # (the plain stepper: 3689)
     assert isa.kernel_stats(blob, "rmt_n2_rk4_reg_redo")["whole"]["valu"] > 3000        # the plain stepper, same object
+    lds = isa.kernel_resources(blob, "rmt_n2_rk4_reg")["group_segment_fixed_size"]      # the plan's LDS estimate holds
+    assert lds <= 160*1024 and abs(lds - dme._kcache_lds(False, 512, 2, 1, "basis", True, True)) < 4096
+    assert isa.kernel_resources(blob, "rmt_n2_rk4_reg_redo")["group_segment_fixed_size"] < 80*1024    # (the big exp table)
     _, row4 = plan.member_constants(INP.dme_notebook_input(), dme, 4096)
     block, npt, defs, src, key = device_source(dme, np.tile(row4, (256, 1)), 4096)
     assert (block, npt) == (512, 2) and defs["RMT_KCACHE_CHAIN"] == "1" and "#define RMT_LDS_STATE_CHAIN 1" in src
